@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: batched 1D N=4096 fp16 C2C FFT (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one tfft_exec over one resident batch of 65536 transforms (2^28 complex samples, 1 GiB in +
+1 GiB out in HBM). With N GPUs every rank owns its own batch of the same size (the batch shards with no
+data-path collective: SURVEY 8e), so scaling is weak and `value` is the aggregate over all ranks.
+
+Rank 0 prints ONE JSON line. `roofline` is the HBM roofline of the dominant kernel (algorithmic bytes =
+8 B per complex sample per launch: 4 read + 4 written) with the launch duration measured here
+by HIP events on the launch stream. `cpu_baseline` is the CPU oracle's fp64 FFT (oracle/, a port: the
+reference has no CPU path, its oracle is cuFFT on the GPU) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N = 4096
+BATCH = 65536
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16 MFMA
+
+
+def cpu_baseline(seconds_target=12.0):
+    """fp64 radix-2 FFT/N of the oracle over OpenMP threads on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import orc
+
+    threads = orc.num_threads()
+    rng = np.random.default_rng(0)
+    probe = 64 * threads
+    re = rng.uniform(-1, 1, (probe, N)).astype(np.float16)
+    im = rng.uniform(-1, 1, (probe, N)).astype(np.float16)
+    orc.dft64(re[:threads], im[:threads])                       # warm
+    t0 = time.perf_counter()
+    orc.dft64(re, im)
+    rate = probe / (time.perf_counter() - t0)                    # FFTs / s
+    count = int(max(probe, min(BATCH, rate * seconds_target)))
+    reps = -(-count // probe)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.dft64(re, im)
+    dt = time.perf_counter() - t0
+    done = reps * probe
+    return {
+        "value": done * N / dt / 1e9,
+        "unit": "Gsamples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{done} of {BATCH} FFTs (N={N}), oracle fp64 radix-2 FFT/N, OpenMP over the batch, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="transforms per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+
+    g.build()
+    import tensor_fft_amd as tf
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL: barrier + max only
+
+    tf.device_check(local_rank)
+    batch = args.batch
+    gen = torch.Generator(device="cuda").manual_seed(42 + rank)
+    # synthetic planar fp16, uniform(-1,1), DataBatchHandler layout [fft_i RE | fft_i IM], resident in HBM
+    x = torch.empty(batch * 2 * N, dtype=torch.float16, device="cuda")
+    chunk = 1 << 26
+    for s in range(0, x.numel(), chunk):
+        e = min(x.numel(), s + chunk)
+        x[s:e] = (torch.rand(e - s, device="cuda", generator=gen) * 2 - 1).to(torch.float16)
+    y = torch.empty_like(x)
+    plan = tf.TfftPlan(N, batch, local_rank, preserve_input=True)
+
+    def step():
+        plan.exec(x, x[N:], y, y[N:])
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps            # launches are back to back on one stream
+    if dist is not None:
+        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(t[0]), float(t[1])
+
+    # light self-check so a broken kernel cannot post a number: Parseval on a slice
+    xs = x[: 64 * 2 * N].float().reshape(64, 2 * N)
+    ys = y[: 64 * 2 * N].float().reshape(64, 2 * N)
+    par = float((((ys ** 2).sum(1) - (xs ** 2).sum(1) / N).abs() / ((xs ** 2).sum(1) / N)).max())
+    if not par < 5e-3:
+        raise SystemExit(f"self-check failed: Parseval mismatch {par:.3e}")
+
+    if rank == 0:
+        samples_per_step = float(N) * batch * world
+        value = samples_per_step * args.steps / wall / 1e9
+        alg_bytes = plan.algorithmic_bytes                      # per launch, this rank
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        mfma_tflops = plan.mfma_flops / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "Gsamples/s + %fp16-MFMA-peak, batched N=4096 fp16 C2C FFT",
+            "value": value,
+            "unit": "Gsamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: batched 1D N=4096 fp16 C2C FFT, batch=65536 per GPU, "
+                            "planar [RE|IM] blocks resident in HBM, result = DFT(x)/N",
+                "n": N,
+                "batch_per_gpu": batch,
+                "parallelism": f"batch sharded over {world} GPU(s), no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": plan.kernel_name,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+            },
+            "mfma": {"tflops": mfma_tflops, "peak": MFMA_PEAK_TFLOPS, "frac": mfma_tflops / MFMA_PEAK_TFLOPS,
+                     "flop_per_sample": 384},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

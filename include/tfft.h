@@ -1,0 +1,134 @@
+/* tfft.h — C ABI of the MI355X (gfx950) tensor-core FFT library (libtfft.so).
+ *
+ * Drop-in boundary for ONE path of CPestka/Tensor-FFT: the src/base batched,
+ * forward, 1/N-scaled, planar-fp16 complex-to-complex 1D FFT. Each entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * repository root). Only plain pointers and sizes cross this boundary: device
+ * pointers are raw HIP device addresses, `stream` is a hipStream_t passed as
+ * void*. No torch / C++ types.
+ *
+ * Data contract (identical to the reference kernels' signature
+ * `__half* in_RE, __half* in_IM, __half* out_RE, __half* out_IM`,
+ * src/base/TensorFFT256.cu:21-24): split ("planar") IEEE binary16 planes; FFT b
+ * of a batch lives at plane_ptr + b * batch_stride halves, where the default
+ * batch_stride = 2*N reproduces DataBatchHandler's [fft0_RE|fft0_IM|fft1_RE|..]
+ * block (src/base/DataHandler.h:105-114). Result = DFT(x)/N with the sign
+ * exp(-2 pi i jk/N) (the reference's "sequential scaling",
+ * src/base/TensorFFT4096.cu:169-173, TensorRadix16.cu:132-136, Radix2.cu:67-76).
+ */
+#ifndef TFFT_H_
+#define TFFT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tfft_plan tfft_plan;
+
+/* Status codes. 0 = success, mirroring the reference's `std::nullopt == OK`
+ * convention (src/base/ComputeFFT.h:147-150); the message of the last failure on
+ * the calling thread is available from tfft_last_error(). */
+enum {
+  TFFT_OK = 0,
+  TFFT_ERR_NOT_POW2 = 1,   /* Plan.h:85-88  "Input size has to be a power of 2" */
+  TFFT_ERR_TOO_SMALL = 2,  /* Plan.h:92-96  N < 256 for a reference-compatible plan */
+  TFFT_ERR_MODE = 3,       /* Plan.h:102-106 Mode_4096 with N < 4096 */
+  TFFT_ERR_GEOMETRY = 4,   /* Plan.h:128-133,162-167,184-190 divisibility of warps / r2 block */
+  TFFT_ERR_ARG = 5,        /* null / misaligned pointer, bad stride, bad batch */
+  TFFT_ERR_DEVICE = 6,     /* not a gfx950 / wave64 / 160 KiB-LDS device (Plan.h:257-296) */
+  TFFT_ERR_HIP = 7,        /* a HIP runtime call failed; text in tfft_last_error() */
+  TFFT_ERR_WORKSPACE = 8   /* workspace needed but missing / too small */
+};
+
+/* BaseFFTMode of the reference (src/base/Plan.h:14). */
+enum { TFFT_MODE_256 = 0, TFFT_MODE_4096 = 1 };
+
+/* Field-for-field image of `struct Plan<Integer>` (src/base/Plan.h:18-39) as
+ * CreatePlan() fills it (Plan.h:77-194). The launch-geometry fields are kept
+ * so that code which prints / tunes them still works; the MI355X kernels do
+ * not consume them. */
+typedef struct tfft_ref_plan {
+  uint64_t fft_length;
+  int amount_of_r16_steps;
+  int amount_of_r2_steps;
+  int base_fft_mode;
+  int results_in_results;
+  int base_fft_warps_per_block;
+  int base_fft_blocksize;
+  int base_fft_gridsize;
+  int base_fft_shared_mem_in_bytes;
+  int r16_warps_per_block;
+  int r16_blocksize;
+  int r16_gridsize;
+  int r16_shared_mem_in_bytes;
+  int r2_blocksize;
+} tfft_ref_plan;
+
+/* Replaces CreatePlan(fft_length, mode, base_fft_warps_per_block,
+ * r16_warps_per_block, r2_blocksize) (src/base/Plan.h:77-194). Host only. Same
+ * acceptance rules, same derived fields, same warp-count overrides (the
+ * warnings the reference prints are returned through tfft_last_error()). */
+int tfft_ref_create_plan(uint64_t fft_length, int mode, int base_fft_warps_per_block,
+                         int r16_warps_per_block, int r2_blocksize, tfft_ref_plan* out);
+
+/* Replaces PlanWorksOnDevice(plan, device_id) (src/base/Plan.h:257-296): the
+ * CC>=8 / warp==32 checks become gfx950 / wave64 / 160 KiB LDS. Returns TFFT_OK
+ * or TFFT_ERR_DEVICE / TFFT_ERR_HIP. */
+int tfft_device_check(int device_id);
+
+/* Replaces GetMaxNoOptInSharedMem(device_id) (src/base/Plan.h:298-303):
+ * sharedMemPerBlock of the device, or -1 on error. */
+int tfft_max_no_optin_shared_mem(int device_id);
+
+/* Execution plan for `batch` transforms of length n on `device_id`.
+ * n: power of two >= 2 (the reference-compatible shim enforces >= 256).
+ * in/out_batch_stride: distance in halves between consecutive FFTs of a plane;
+ * 0 selects the DataBatchHandler default 2*n. Must be a multiple of 8.
+ * The plan is immutable after creation and may be shared between host threads;
+ * it owns small device-side constant tables (and a workspace if it allocated one). */
+typedef struct tfft_plan_opts {
+  uint64_t in_batch_stride;
+  uint64_t out_batch_stride;
+  int preserve_input;   /* 0: the input planes may be used as scratch, exactly as the
+                           reference does (ComputeFFT.h:89-93,118-119); 1: never written */
+  int reserved;
+} tfft_plan_opts;
+
+int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts,
+                     tfft_plan** out);
+void tfft_plan_destroy(tfft_plan* plan);
+
+/* Number of kernel launches one tfft_exec issues and the bytes of device scratch
+ * it needs beyond in/out (0 for N == 4096). If nonzero, either hand memory in
+ * with tfft_plan_set_workspace() or let the first tfft_exec hipMalloc it. */
+int tfft_plan_num_launches(const tfft_plan* plan);
+size_t tfft_plan_workspace_bytes(const tfft_plan* plan);
+int tfft_plan_set_workspace(tfft_plan* plan, void* device_ptr, size_t bytes);
+
+/* Replaces ComputeFFT(Plan&, const DataHandler&, int) and ComputeFFT(const Plan&,
+ * const DataBatchHandler&, int) (src/base/ComputeFFT.h:54-151, 162-293): enqueues
+ * the whole batch on `stream` (hipStream_t, may be NULL = default stream). Like the
+ * single-FFT overload it does not synchronise (ComputeFFT.h:49-53); unlike the
+ * batch overload it creates no streams. The result is always left in out_*
+ * (results_in_results_ == true in reference terms); out may alias in (in place).
+ * Pointers must be 16-byte aligned. */
+int tfft_exec(const tfft_plan* plan, const void* in_re, const void* in_im, void* out_re,
+              void* out_im, void* stream);
+
+/* Name of the dominant kernel of this plan (for profiler summaries) and the
+ * algorithmic HBM bytes / MFMA flops of one tfft_exec (SURVEY 8d accounting). */
+const char* tfft_plan_kernel_name(const tfft_plan* plan);
+double tfft_plan_algorithmic_bytes(const tfft_plan* plan);
+double tfft_plan_mfma_flops(const tfft_plan* plan);
+
+/* Message of the last error (or warning) raised on this thread; "" if none. */
+const char* tfft_last_error(void);
+const char* tfft_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFFT_H_ */

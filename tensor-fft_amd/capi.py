@@ -1,0 +1,196 @@
+"""ctypes binding of include/tfft.h (libtfft.so). No fallback of any kind."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libtfft.so"
+
+TFFT_OK = 0
+ERR_NAMES = {
+    1: "TFFT_ERR_NOT_POW2", 2: "TFFT_ERR_TOO_SMALL", 3: "TFFT_ERR_MODE", 4: "TFFT_ERR_GEOMETRY",
+    5: "TFFT_ERR_ARG", 6: "TFFT_ERR_DEVICE", 7: "TFFT_ERR_HIP", 8: "TFFT_ERR_WORKSPACE",
+}
+
+# every symbol include/tfft.h declares (tests check that the library exports them all)
+SYMBOLS = [
+    "tfft_ref_create_plan", "tfft_device_check", "tfft_max_no_optin_shared_mem", "tfft_plan_create",
+    "tfft_plan_destroy", "tfft_plan_num_launches", "tfft_plan_workspace_bytes", "tfft_plan_set_workspace",
+    "tfft_exec", "tfft_plan_kernel_name", "tfft_plan_algorithmic_bytes", "tfft_plan_mfma_flops",
+    "tfft_last_error", "tfft_version",
+]
+
+
+class TfftError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {message}")
+        self.code = code
+        self.message = message
+
+
+class RefPlanStruct(ctypes.Structure):
+    """tfft_ref_plan == struct Plan<Integer> of the reference (src/base/Plan.h:18-39)."""
+    _fields_ = [
+        ("fft_length", ctypes.c_uint64),
+        ("amount_of_r16_steps", ctypes.c_int),
+        ("amount_of_r2_steps", ctypes.c_int),
+        ("base_fft_mode", ctypes.c_int),
+        ("results_in_results", ctypes.c_int),
+        ("base_fft_warps_per_block", ctypes.c_int),
+        ("base_fft_blocksize", ctypes.c_int),
+        ("base_fft_gridsize", ctypes.c_int),
+        ("base_fft_shared_mem_in_bytes", ctypes.c_int),
+        ("r16_warps_per_block", ctypes.c_int),
+        ("r16_blocksize", ctypes.c_int),
+        ("r16_gridsize", ctypes.c_int),
+        ("r16_shared_mem_in_bytes", ctypes.c_int),
+        ("r2_blocksize", ctypes.c_int),
+    ]
+
+
+class PlanOpts(ctypes.Structure):
+    _fields_ = [
+        ("in_batch_stride", ctypes.c_uint64),
+        ("out_batch_stride", ctypes.c_uint64),
+        ("preserve_input", ctypes.c_int),
+        ("reserved", ctypes.c_int),
+    ]
+
+
+def lib_path():
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libtfft.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` from the repository root.")
+    L = ctypes.CDLL(path)
+    vp, u64, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
+    L.tfft_ref_create_plan.restype = ci
+    L.tfft_ref_create_plan.argtypes = [u64, ci, ci, ci, ci, ctypes.POINTER(RefPlanStruct)]
+    L.tfft_device_check.restype = ci
+    L.tfft_device_check.argtypes = [ci]
+    L.tfft_max_no_optin_shared_mem.restype = ci
+    L.tfft_max_no_optin_shared_mem.argtypes = [ci]
+    L.tfft_plan_create.restype = ci
+    L.tfft_plan_create.argtypes = [u64, u64, ci, ctypes.POINTER(PlanOpts), ctypes.POINTER(vp)]
+    L.tfft_plan_destroy.restype = None
+    L.tfft_plan_destroy.argtypes = [vp]
+    L.tfft_plan_num_launches.restype = ci
+    L.tfft_plan_num_launches.argtypes = [vp]
+    L.tfft_plan_workspace_bytes.restype = ctypes.c_size_t
+    L.tfft_plan_workspace_bytes.argtypes = [vp]
+    L.tfft_plan_set_workspace.restype = ci
+    L.tfft_plan_set_workspace.argtypes = [vp, vp, ctypes.c_size_t]
+    L.tfft_exec.restype = ci
+    L.tfft_exec.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.tfft_plan_kernel_name.restype = ctypes.c_char_p
+    L.tfft_plan_kernel_name.argtypes = [vp]
+    L.tfft_plan_algorithmic_bytes.restype = ctypes.c_double
+    L.tfft_plan_algorithmic_bytes.argtypes = [vp]
+    L.tfft_plan_mfma_flops.restype = ctypes.c_double
+    L.tfft_plan_mfma_flops.argtypes = [vp]
+    L.tfft_last_error.restype = ctypes.c_char_p
+    L.tfft_last_error.argtypes = []
+    L.tfft_version.restype = ctypes.c_char_p
+    L.tfft_version.argtypes = []
+    _lib = L
+    return L
+
+
+def last_error():
+    return load_library().tfft_last_error().decode()
+
+
+def _check(rc):
+    if rc != TFFT_OK:
+        raise TfftError(rc, last_error())
+
+
+def ref_create_plan(fft_length, mode=0, base_fft_warps_per_block=8, r16_warps_per_block=8, r2_blocksize=256):
+    """tfft_ref_create_plan -> (rc, RefPlanStruct, message). Host only, no GPU needed."""
+    L = load_library()
+    s = RefPlanStruct()
+    rc = L.tfft_ref_create_plan(int(fft_length), int(mode), int(base_fft_warps_per_block),
+                                int(r16_warps_per_block), int(r2_blocksize), ctypes.byref(s))
+    return rc, s, last_error()
+
+
+def device_check(device_id=0):
+    _check(load_library().tfft_device_check(int(device_id)))
+
+
+class TfftPlan:
+    """Owning wrapper of tfft_plan. exec() takes torch CUDA half tensors (planar)."""
+
+    def __init__(self, n, batch=1, device=0, in_batch_stride=0, out_batch_stride=0, preserve_input=False):
+        L = load_library()
+        self._lib = L
+        self._h = ctypes.c_void_p()
+        opts = PlanOpts(int(in_batch_stride), int(out_batch_stride), int(bool(preserve_input)), 0)
+        _check(L.tfft_plan_create(int(n), int(batch), int(device), ctypes.byref(opts), ctypes.byref(self._h)))
+        self.n, self.batch, self.device = int(n), int(batch), int(device)
+        self.in_batch_stride = int(in_batch_stride) or 2 * self.n
+        self.out_batch_stride = int(out_batch_stride) or 2 * self.n
+        self._ws = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.tfft_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    @property
+    def num_launches(self):
+        return self._lib.tfft_plan_num_launches(self._h)
+
+    @property
+    def workspace_bytes(self):
+        return self._lib.tfft_plan_workspace_bytes(self._h)
+
+    @property
+    def kernel_name(self):
+        return self._lib.tfft_plan_kernel_name(self._h).decode()
+
+    @property
+    def algorithmic_bytes(self):
+        return self._lib.tfft_plan_algorithmic_bytes(self._h)
+
+    @property
+    def mfma_flops(self):
+        return self._lib.tfft_plan_mfma_flops(self._h)
+
+    def set_workspace(self, tensor):
+        """Hands a torch CUDA tensor in as scratch (kept alive by the plan)."""
+        self._ws = tensor
+        _check(self._lib.tfft_plan_set_workspace(self._h, tensor.data_ptr(), tensor.numel() * tensor.element_size()))
+
+    def exec_ptr(self, in_re, in_im, out_re, out_im, stream=0):
+        _check(self._lib.tfft_exec(self._h, in_re, in_im, out_re, out_im, stream))
+
+    def exec(self, in_re, in_im, out_re, out_im, stream=None):
+        import torch
+
+        for t in (in_re, in_im, out_re, out_im):
+            if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()):
+                raise TfftError(5, "planes must be contiguous CUDA float16 tensors")
+            if t.device.index != self.device:
+                raise TfftError(5, "tensor on another device than the plan")
+        need_in = (self.batch - 1) * self.in_batch_stride + self.n
+        need_out = (self.batch - 1) * self.out_batch_stride + self.n
+        if in_re.numel() < need_in or in_im.numel() < need_in or out_re.numel() < need_out or out_im.numel() < need_out:
+            raise TfftError(5, "a plane is shorter than (batch-1)*stride + N")
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            self.exec_ptr(in_re.data_ptr(), in_im.data_ptr(), out_re.data_ptr(), out_im.data_ptr(), stream)

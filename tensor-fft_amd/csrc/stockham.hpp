@@ -1,0 +1,177 @@
+// stockham.hpp — generic batched radix-{2,4,8,16} autosort passes through HBM.
+//
+// Covers every power-of-two N that has no dedicated LDS-resident kernel yet. It
+// stands where the reference chains TensorFFT256 -> TensorRadix16* -> Radix2Kernel*
+// (src/base/ComputeFFT.h:72-145; kernels TensorRadix16.cu:36-214, Radix2.cu:20-77)
+// and keeps its contract: one full read + one full write of the array per pass,
+// ping-pong between two buffers, 1/radix scaling per pass (TensorRadix16.cu:132-136,
+// Radix2.cu:67-76). Differences: one launch per pass for the WHOLE batch (the
+// reference launches per FFT and, for radix 2, per pair of sub-FFTs:
+// ComputeFFT.h:123-138); autosort indexing instead of an up-front digit-reversal
+// gather (TensorFFT256.cu:125-178), so reads are always contiguous over the
+// thread index; butterflies in fp32 registers; twiddles from a two-level fp32
+// table computed in fp64 on the host instead of per-element cosf/sinf
+// (TensorRadix16.cu:117-125).
+//
+// Pass with sub-transform length Ns (Ns = product of the radices already done):
+//   j in [0, N/R):  k = j mod Ns
+//   v[i] = x[j + i N/R] * w_{Ns R}^(i k),  i = 0..R-1
+//   y[(j - k) R + k + i Ns] = DFT_R(v)[i] / R
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace stockham {
+
+constexpr int kBlock = 256;
+constexpr int kTwLoBits = 13;                 // w_N^e = lo[e & 8191] * hi[e >> 13]
+constexpr uint32_t kTwLoSize = 1u << kTwLoBits;
+
+struct cf {
+  float re, im;
+};
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cf mul_mi(cf a) { return {a.im, -a.re}; }     // a * (-i)
+
+// forward DFT-4, natural order in and out
+__device__ __forceinline__ void dft4(cf& a, cf& b, cf& c, cf& d) {
+  const cf s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = mul_mi(csub(b, d));
+  a = cadd(s0, s2);
+  b = cadd(s1, s3);
+  c = csub(s0, s2);
+  d = csub(s1, s3);
+}
+
+template <int R>
+__device__ __forceinline__ void dft(cf (&v)[R]);
+
+template <>
+__device__ __forceinline__ void dft<2>(cf (&v)[2]) {
+  const cf a = v[0], b = v[1];
+  v[0] = cadd(a, b);
+  v[1] = csub(a, b);
+}
+template <>
+__device__ __forceinline__ void dft<4>(cf (&v)[4]) {
+  dft4(v[0], v[1], v[2], v[3]);
+}
+// n = n0 + 4 n1 (n0<4, n1<2), k = k0 + 2 k1 (k0<2, k1<4)
+template <>
+__device__ __forceinline__ void dft<8>(cf (&v)[8]) {
+  const float h = 0.70710678118654752f;
+  cf y[4][2];
+#pragma unroll
+  for (int n0 = 0; n0 < 4; ++n0) {
+    y[n0][0] = cadd(v[n0], v[n0 + 4]);
+    y[n0][1] = csub(v[n0], v[n0 + 4]);
+  }
+  // y[n0][1] *= w8^n0
+  y[1][1] = cmul(y[1][1], cf{h, -h});
+  y[2][1] = mul_mi(y[2][1]);
+  y[3][1] = cmul(y[3][1], cf{-h, -h});
+#pragma unroll
+  for (int k0 = 0; k0 < 2; ++k0) {
+    cf a = y[0][k0], b = y[1][k0], c = y[2][k0], d = y[3][k0];
+    dft4(a, b, c, d);
+    v[k0] = a;
+    v[k0 + 2] = b;
+    v[k0 + 4] = c;
+    v[k0 + 6] = d;
+  }
+}
+// n = n0 + 4 n1, k = k0 + 4 k1
+template <>
+__device__ __forceinline__ void dft<16>(cf (&v)[16]) {
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  // w16^e for e = 0..9 (only products n0*k0 <= 9 occur)
+  const cf w[10] = {{1.f, 0.f}, {c1, -s1}, {h, -h},   {s1, -c1},  {0.f, -1.f},
+                    {-s1, -c1}, {-h, -h},  {-c1, -s1}, {-1.f, 0.f}, {-c1, s1}};
+  cf y[4][4];
+#pragma unroll
+  for (int n0 = 0; n0 < 4; ++n0) {
+    cf a = v[n0], b = v[n0 + 4], c = v[n0 + 8], d = v[n0 + 12];
+    dft4(a, b, c, d);
+    y[n0][0] = a;
+    y[n0][1] = b;
+    y[n0][2] = c;
+    y[n0][3] = d;
+  }
+#pragma unroll
+  for (int n0 = 1; n0 < 4; ++n0)
+#pragma unroll
+    for (int k0 = 1; k0 < 4; ++k0) y[n0][k0] = cmul(y[n0][k0], w[n0 * k0]);
+#pragma unroll
+  for (int k0 = 0; k0 < 4; ++k0) {
+    cf a = y[0][k0], b = y[1][k0], c = y[2][k0], d = y[3][k0];
+    dft4(a, b, c, d);
+    v[k0] = a;
+    v[k0 + 4] = b;
+    v[k0 + 8] = c;
+    v[k0 + 12] = d;
+  }
+}
+
+struct PassArgs {
+  const _Float16* in_re;
+  const _Float16* in_im;
+  _Float16* out_re;
+  _Float16* out_im;
+  uint64_t in_stride;    // halves between FFTs
+  uint64_t out_stride;
+  uint64_t n;            // FFT length
+  uint64_t ns;           // sub-transform length before this pass
+  uint64_t tw_mul;       // N / (Ns * R): exponent of w_N per unit of i*k
+  uint64_t blocks_per_fft;
+  const float2* tw_lo;   // w_N^e, e < min(N, 8192)
+  const float2* tw_hi;   // w_N^(e * 8192), e < N / 8192 (unused when N <= 8192)
+};
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void pass_kernel(PassArgs a) {
+  const uint64_t fft = blockIdx.x / a.blocks_per_fft;
+  const uint64_t j = (blockIdx.x % a.blocks_per_fft) * kBlock + threadIdx.x;
+  const uint64_t m = a.n / R;
+  if (j >= m) return;
+  const uint64_t k = j & (a.ns - 1);
+  const _Float16* xr = a.in_re + fft * a.in_stride + j;
+  const _Float16* xi = a.in_im + fft * a.in_stride + j;
+  cf v[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) v[i] = cf{static_cast<float>(xr[i * m]), static_cast<float>(xi[i * m])};
+  if (a.ns > 1) {
+    const uint64_t step = k * a.tw_mul;      // < N / R
+#pragma unroll
+    for (int i = 1; i < R; ++i) {
+      const uint64_t e = (i * step) & (a.n - 1);
+      const float2 lo = a.tw_lo[e & (kTwLoSize - 1)];
+      cf w = {lo.x, lo.y};
+      if (a.n > kTwLoSize) {
+        const float2 hi = a.tw_hi[e >> kTwLoBits];
+        w = cmul(w, cf{hi.x, hi.y});
+      }
+      v[i] = cmul(v[i], w);
+    }
+  }
+  dft<R>(v);
+  const float sc = 1.0f / R;
+  _Float16* yr = a.out_re + fft * a.out_stride + (j - k) * R + k;
+  _Float16* yi = a.out_im + fft * a.out_stride + (j - k) * R + k;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    yr[i * a.ns] = static_cast<_Float16>(v[i].re * sc);
+    yi[i * a.ns] = static_cast<_Float16>(v[i].im * sc);
+  }
+}
+
+// plain planar copy (in-place requests whose pass chain cannot start from `in`)
+__global__ __launch_bounds__(kBlock) void copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                       uint64_t n32) {
+  for (uint64_t i = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; i < n32;
+       i += static_cast<uint64_t>(gridDim.x) * kBlock)
+    dst[i] = src[i];
+}
+
+}  // namespace stockham

@@ -1,0 +1,403 @@
+// tfft.hip — C ABI (include/tfft.h) over the gfx950 kernels. Built into
+// tensor-fft_amd/libtfft.so by __graft_entry__.build() (hipcc --offload-arch=gfx950).
+//
+// Host side of the hot path: what CreatePlan / PlanWorksOnDevice / ComputeFFT do in
+// the reference (src/base/Plan.h:77-303, src/base/ComputeFFT.h:54-293), re-cut for
+// one process per GPU and explicit streams.
+#include "../../include/tfft.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "k4096.hpp"
+#include "stockham.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  return fail(TFFT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define TFFT_HIP(call)                                  \
+  do {                                                  \
+    hipError_t e_ = (call);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);   \
+  } while (0)
+
+inline bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
+inline int ilog2(uint64_t x) {
+  int l = 0;
+  while ((x >> l) > 1) ++l;
+  return l;
+}
+
+enum class Kind { K4096, Stockham };
+
+struct Pass {
+  int radix;
+  uint64_t ns;
+};
+
+}  // namespace
+
+struct tfft_plan {
+  uint64_t n = 0, batch = 0;
+  int device = 0;
+  uint64_t in_stride = 0, out_stride = 0;
+  bool preserve_input = false;
+  Kind kind = Kind::Stockham;
+  int num_cus = 0;
+  // K4096
+  void* d_tables = nullptr;
+  // Stockham
+  std::vector<Pass> passes;
+  float2* d_tw_lo = nullptr;
+  float2* d_tw_hi = nullptr;
+  // scratch: one [batch][2n] block of halves
+  mutable std::mutex ws_mutex;
+  mutable void* ws = nullptr;
+  mutable size_t ws_bytes = 0;
+  mutable bool ws_owned = false;
+};
+
+namespace {
+
+int launch_k4096(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                 hipStream_t s) {
+  const uint32_t blocks_needed =
+      static_cast<uint32_t>((p->batch + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
+  const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
+  hipLaunchKernelGGL(k4096::fft4096_kernel, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+                     static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), p->in_stride,
+                     p->out_stride, static_cast<uint32_t>(p->batch),
+                     static_cast<const uint8_t*>(p->d_tables));
+  TFFT_HIP(hipGetLastError());
+  return TFFT_OK;
+}
+
+template <int R>
+void launch_pass(const stockham::PassArgs& a, uint64_t batch, hipStream_t s) {
+  const uint64_t grid = a.blocks_per_fft * batch;
+  hipLaunchKernelGGL(stockham::pass_kernel<R>, dim3(static_cast<uint32_t>(grid)), dim3(stockham::kBlock), 0,
+                     s, a);
+}
+
+struct Planes {
+  _Float16* re;
+  _Float16* im;
+  uint64_t stride;
+};
+
+int ensure_workspace(const tfft_plan* p) {
+  std::lock_guard<std::mutex> lock(p->ws_mutex);
+  const size_t need = tfft_plan_workspace_bytes(p);
+  if (need == 0 || (p->ws && p->ws_bytes >= need)) return TFFT_OK;
+  if (p->ws && !p->ws_owned) return fail(TFFT_ERR_WORKSPACE, "workspace handed to tfft_plan_set_workspace is too small");
+  if (p->ws) (void)hipFree(p->ws);
+  p->ws = nullptr;
+  TFFT_HIP(hipMalloc(&p->ws, need));
+  p->ws_bytes = need;
+  p->ws_owned = true;
+  return TFFT_OK;
+}
+
+int launch_stockham(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                    hipStream_t s) {
+  const int np = static_cast<int>(p->passes.size());
+  Planes IN{const_cast<_Float16*>(static_cast<const _Float16*>(in_re)),
+            const_cast<_Float16*>(static_cast<const _Float16*>(in_im)), p->in_stride};
+  Planes OUT{static_cast<_Float16*>(out_re), static_cast<_Float16*>(out_im), p->out_stride};
+  const bool in_place = (in_re == out_re) || (in_im == out_im);
+  // Targets alternate OUT / SCR so that the last pass writes OUT. SCR is the input
+  // block when the reference's "input is scratch" contract allows it and the chain
+  // does not start by overwriting what it reads; otherwise the plan's workspace.
+  const bool odd = (np % 2) == 1;
+  const bool use_in_as_scratch = !p->preserve_input && !in_place && odd;
+  Planes SCR = IN;
+  Planes SRC = IN;
+  if (!use_in_as_scratch && (np > 1 || in_place)) {
+    const int rc = ensure_workspace(p);
+    if (rc) return rc;
+    _Float16* w = static_cast<_Float16*>(p->ws);
+    SCR = Planes{w, w + p->n, 2 * p->n};
+    if (in_place && odd) {
+      // chain IN -> OUT would read and write the same block: start from a copy.
+      if (p->in_stride != 2 * p->n || static_cast<const _Float16*>(in_im) != static_cast<const _Float16*>(in_re) + p->n)
+        return fail(TFFT_ERR_ARG, "in-place execution of this length needs the [RE|IM] block layout (batch stride 2N)");
+      const uint64_t n32 = p->batch * p->n;          // 4 bytes per complex sample
+      hipLaunchKernelGGL(stockham::copy_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>((n32 + 255) / 256, 8192))),
+                         dim3(stockham::kBlock), 0, s, static_cast<const uint32_t*>(in_re), static_cast<uint32_t*>(p->ws), n32);
+      SRC = SCR;
+      // second scratch is not available: alternate OUT / WS still works because the
+      // first pass reads WS and writes OUT, the next reads OUT and writes WS, ...
+    }
+  }
+  Planes cur = SRC;
+  for (int i = 0; i < np; ++i) {
+    const bool to_out = ((np - 1 - i) % 2) == 0;
+    Planes dst = to_out ? OUT : SCR;
+    stockham::PassArgs a;
+    a.in_re = cur.re;
+    a.in_im = cur.im;
+    a.out_re = dst.re;
+    a.out_im = dst.im;
+    a.in_stride = cur.stride;
+    a.out_stride = dst.stride;
+    a.n = p->n;
+    a.ns = p->passes[i].ns;
+    const int R = p->passes[i].radix;
+    a.tw_mul = p->n / (a.ns * R);
+    a.blocks_per_fft = (p->n / R + stockham::kBlock - 1) / stockham::kBlock;
+    a.tw_lo = p->d_tw_lo;
+    a.tw_hi = p->d_tw_hi;
+    switch (R) {
+      case 2: launch_pass<2>(a, p->batch, s); break;
+      case 4: launch_pass<4>(a, p->batch, s); break;
+      case 8: launch_pass<8>(a, p->batch, s); break;
+      default: launch_pass<16>(a, p->batch, s); break;
+    }
+    cur = dst;
+  }
+  TFFT_HIP(hipGetLastError());
+  return TFFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tfft_last_error(void) { return g_err.c_str(); }
+const char* tfft_version(void) { return "tfft 0.1 (gfx950)"; }
+
+int tfft_ref_create_plan(uint64_t n, int mode, int base_wpb, int r16_wpb, int r2_bs, tfft_ref_plan* out) {
+  g_err.clear();
+  if (!out) return fail(TFFT_ERR_ARG, "null plan pointer");
+  if (!is_pow2(n)) return fail(TFFT_ERR_NOT_POW2, "Error! Input size has to be a power of 2!");
+  const int lg = ilog2(n);
+  if (lg < 8) return fail(TFFT_ERR_TOO_SMALL, "Error! Input size has to be larger than 256 i.e. 16^2");
+  if (mode != TFFT_MODE_256 && mode != TFFT_MODE_4096) return fail(TFFT_ERR_MODE, "unknown base FFT mode");
+  if (mode == TFFT_MODE_4096 && n < 4096)
+    return fail(TFFT_ERR_MODE, "Error! Baselayer fft length cant be longer that fft_length.");
+  if (base_wpb <= 0 || r16_wpb <= 0 || r2_bs <= 0) return fail(TFFT_ERR_ARG, "non-positive launch parameter");
+  tfft_ref_plan pl;
+  std::memset(&pl, 0, sizeof(pl));
+  pl.fft_length = n;
+  pl.amount_of_r16_steps = lg / 4 - 1;
+  pl.amount_of_r2_steps = lg % 4;
+  pl.base_fft_mode = mode;
+  const int after_base = pl.amount_of_r16_steps + pl.amount_of_r2_steps - (mode == TFFT_MODE_256 ? 1 : 2);
+  pl.results_in_results = (after_base % 2 == 0) ? 1 : 0;
+  const uint64_t warps = n / 256;
+  std::string warn;
+  if (warps < static_cast<uint64_t>(base_wpb)) {
+    pl.base_fft_warps_per_block = static_cast<int>(warps);
+    warn += "Warning! base_fft_warps_per_block overwritten to total_amount_of_warps. ";
+  } else {
+    if (warps % base_wpb) return fail(TFFT_ERR_GEOMETRY, "Error! Total amount of warps (fft_length/256) has to be evenly devisable by base_fft_warps_per_block.");
+    if (mode == TFFT_MODE_4096) {
+      if (base_wpb != 16) warn += "Warning! base_fft_warps_per_block overwritten to 16 (mandatory for mode=4096). ";
+      pl.base_fft_warps_per_block = 16;
+    } else {
+      pl.base_fft_warps_per_block = base_wpb;
+    }
+  }
+  pl.base_fft_blocksize = pl.base_fft_warps_per_block * 32;
+  pl.base_fft_gridsize = static_cast<int>(warps / pl.base_fft_warps_per_block);
+  pl.base_fft_shared_mem_in_bytes = pl.base_fft_warps_per_block * 1024 * 2;
+  if (warps < static_cast<uint64_t>(r16_wpb)) {
+    pl.r16_warps_per_block = static_cast<int>(warps);
+    warn += "Warning! r16_warps_per_block overwritten to total_amount_of_warps. ";
+  } else {
+    if (warps % r16_wpb) return fail(TFFT_ERR_GEOMETRY, "Error! Total amount of warps (fft_length/256) has to be evenly devisable by amount_of_r16_warps_per_block.");
+    pl.r16_warps_per_block = r16_wpb;
+  }
+  pl.r16_blocksize = pl.r16_warps_per_block * 32;
+  pl.r16_gridsize = static_cast<int>(warps / pl.r16_warps_per_block);
+  pl.r16_shared_mem_in_bytes = pl.r16_warps_per_block * 768 * 2;
+  const uint64_t smallest_r2 = n >> pl.amount_of_r2_steps;
+  if (smallest_r2 % r2_bs) return fail(TFFT_ERR_GEOMETRY, "Error! smallest_r2_subfft_length has to be evenly devisable by r2_blocksize.");
+  pl.r2_blocksize = r2_bs;
+  *out = pl;
+  g_err = warn;
+  return TFFT_OK;
+}
+
+int tfft_device_check(int device_id) {
+  g_err.clear();
+  hipDeviceProp_t prop;
+  TFFT_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(TFFT_ERR_DEVICE, std::string("Error! gfx950 (MI355X) is required, found ") + prop.gcnArchName);
+  if (prop.warpSize != 64) return fail(TFFT_ERR_DEVICE, "Error! Wavefront size of 64 required.");
+  if (prop.maxThreadsPerBlock < k4096::kThreads) return fail(TFFT_ERR_DEVICE, "Error! Kernel exceeds max threads per block.");
+  int lds_optin = 0;
+  TFFT_HIP(hipDeviceGetAttribute(&lds_optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id));
+  if (lds_optin < k4096::kLdsBytes) return fail(TFFT_ERR_DEVICE, "Error! Kernel exceeds max shared memory per block (160 KiB LDS needed).");
+  return TFFT_OK;
+}
+
+int tfft_max_no_optin_shared_mem(int device_id) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return -1;
+  return static_cast<int>(prop.sharedMemPerBlock);
+}
+
+int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts, tfft_plan** out) {
+  g_err.clear();
+  if (!out) return fail(TFFT_ERR_ARG, "null plan pointer");
+  *out = nullptr;
+  if (!is_pow2(n)) return fail(TFFT_ERR_NOT_POW2, "Error! Input size has to be a power of 2!");
+  if (n < 2) return fail(TFFT_ERR_TOO_SMALL, "Error! Input size has to be at least 2");
+  if (batch == 0 || batch > 0xffffffffull) return fail(TFFT_ERR_ARG, "batch must be in [1, 2^32)");
+  const uint64_t in_stride = (opts && opts->in_batch_stride) ? opts->in_batch_stride : 2 * n;
+  const uint64_t out_stride = (opts && opts->out_batch_stride) ? opts->out_batch_stride : 2 * n;
+  if (n >= 8 && ((in_stride % 8) || (out_stride % 8))) return fail(TFFT_ERR_ARG, "batch strides must be multiples of 8 halves (16 bytes)");
+  if (in_stride < n || out_stride < n) return fail(TFFT_ERR_ARG, "batch stride smaller than the FFT length");
+  int rc = tfft_device_check(device_id);
+  if (rc) return rc;
+  int prev = 0;
+  TFFT_HIP(hipGetDevice(&prev));
+  TFFT_HIP(hipSetDevice(device_id));
+  tfft_plan* p = new tfft_plan;
+  p->n = n;
+  p->batch = batch;
+  p->device = device_id;
+  p->in_stride = in_stride;
+  p->out_stride = out_stride;
+  p->preserve_input = opts && opts->preserve_input;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device_id);
+  p->num_cus = (e == hipSuccess) ? prop.multiProcessorCount : 256;
+  auto bail = [&](int code) {
+    tfft_plan_destroy(p);
+    (void)hipSetDevice(prev);
+    return code;
+  };
+  if (n == 4096) {
+    p->kind = Kind::K4096;
+    std::vector<uint8_t> blob;
+    k4096::build_tables(blob);
+    e = hipMalloc(&p->d_tables, blob.size());
+    if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(tables)"));
+    e = hipMemcpy(p->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tables)"));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4096::fft4096_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, k4096::kLdsBytes);
+    if (e != hipSuccess) return bail(hip_fail(e, "hipFuncSetAttribute(LDS)"));
+  } else {
+    p->kind = Kind::Stockham;
+    const int lg = ilog2(n);
+    uint64_t ns = 1;
+    if (lg % 4) {
+      p->passes.push_back(Pass{1 << (lg % 4), ns});
+      ns <<= (lg % 4);
+    }
+    for (int i = 0; i < lg / 4; ++i) {
+      p->passes.push_back(Pass{16, ns});
+      ns *= 16;
+    }
+    const uint64_t lo_n = std::min<uint64_t>(n, stockham::kTwLoSize);
+    const uint64_t hi_n = n > stockham::kTwLoSize ? n / stockham::kTwLoSize : 0;
+    std::vector<float2> lo(lo_n), hi(hi_n);
+    for (uint64_t t = 0; t < lo_n; ++t) {
+      const double a = -2.0 * M_PI * static_cast<double>(t) / static_cast<double>(n);
+      lo[t] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+    }
+    for (uint64_t t = 0; t < hi_n; ++t) {
+      const double a = -2.0 * M_PI * static_cast<double>(t) * stockham::kTwLoSize / static_cast<double>(n);
+      hi[t] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+    }
+    e = hipMalloc(reinterpret_cast<void**>(&p->d_tw_lo), lo_n * sizeof(float2));
+    if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(tw_lo)"));
+    e = hipMemcpy(p->d_tw_lo, lo.data(), lo_n * sizeof(float2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tw_lo)"));
+    if (hi_n) {
+      e = hipMalloc(reinterpret_cast<void**>(&p->d_tw_hi), hi_n * sizeof(float2));
+      if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(tw_hi)"));
+      e = hipMemcpy(p->d_tw_hi, hi.data(), hi_n * sizeof(float2), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tw_hi)"));
+    }
+    const uint64_t max_blocks = ((n / 2 + stockham::kBlock - 1) / stockham::kBlock) * batch;
+    if (max_blocks > 0x7fffffffull) return bail(fail(TFFT_ERR_ARG, "batch * N too large for one launch"));
+  }
+  (void)hipSetDevice(prev);
+  *out = p;
+  return TFFT_OK;
+}
+
+void tfft_plan_destroy(tfft_plan* p) {
+  if (!p) return;
+  if (p->d_tables) (void)hipFree(p->d_tables);
+  if (p->d_tw_lo) (void)hipFree(p->d_tw_lo);
+  if (p->d_tw_hi) (void)hipFree(p->d_tw_hi);
+  if (p->ws && p->ws_owned) (void)hipFree(p->ws);
+  delete p;
+}
+
+int tfft_plan_num_launches(const tfft_plan* p) {
+  if (!p) return 0;
+  return p->kind == Kind::K4096 ? 1 : static_cast<int>(p->passes.size());
+}
+
+size_t tfft_plan_workspace_bytes(const tfft_plan* p) {
+  if (!p || p->kind == Kind::K4096) return 0;
+  return static_cast<size_t>(p->batch) * p->n * 4;   // [batch][RE n | IM n] halves
+}
+
+int tfft_plan_set_workspace(tfft_plan* p, void* device_ptr, size_t bytes) {
+  g_err.clear();
+  if (!p) return fail(TFFT_ERR_ARG, "null plan");
+  std::lock_guard<std::mutex> lock(p->ws_mutex);
+  if (p->ws && p->ws_owned) (void)hipFree(p->ws);
+  p->ws = device_ptr;
+  p->ws_bytes = device_ptr ? bytes : 0;
+  p->ws_owned = false;
+  return TFFT_OK;
+}
+
+int tfft_exec(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im, void* stream) {
+  g_err.clear();
+  if (!p) return fail(TFFT_ERR_ARG, "null plan");
+  if (!in_re || !in_im || !out_re || !out_im) return fail(TFFT_ERR_ARG, "null data pointer");
+  const uintptr_t align = (p->n >= 8) ? 15 : (2 * p->n - 1);
+  if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im) | reinterpret_cast<uintptr_t>(out_re) |
+       reinterpret_cast<uintptr_t>(out_im)) & align)
+    return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
+  int cur = 0;
+  TFFT_HIP(hipGetDevice(&cur));
+  if (cur != p->device) return fail(TFFT_ERR_ARG, "plan was created for another device than the current one");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p->kind == Kind::K4096) return launch_k4096(p, in_re, in_im, out_re, out_im, s);
+  return launch_stockham(p, in_re, in_im, out_re, out_im, s);
+}
+
+const char* tfft_plan_kernel_name(const tfft_plan* p) {
+  if (!p) return "";
+  return p->kind == Kind::K4096 ? "fft4096_kernel" : "pass_kernel";
+}
+
+double tfft_plan_algorithmic_bytes(const tfft_plan* p) {
+  if (!p) return 0.0;
+  const double samples = static_cast<double>(p->n) * static_cast<double>(p->batch);
+  return 8.0 * samples * tfft_plan_num_launches(p);   // 4 B read + 4 B written per sample per pass
+}
+
+double tfft_plan_mfma_flops(const tfft_plan* p) {
+  if (!p || p->kind != Kind::K4096) return 0.0;
+  // 3 stages x 16 tiles x 2 MFMA(16x16x32) x 16384 flop per 4096 samples = 384 flop/sample
+  return 384.0 * static_cast<double>(p->n) * static_cast<double>(p->batch);
+}
+
+}  // extern "C"

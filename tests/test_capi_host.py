@@ -1,0 +1,111 @@
+"""Host-side checks of the C ABI that need no GPU: the library loads, exports every symbol
+include/tfft.h declares, and its CreatePlan arithmetic equals the reference's (src/base/Plan.h:77-194)."""
+import os
+import re
+
+import pytest
+
+import tensor_fft_amd as tf
+from tensor_fft_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as g
+
+    g.build()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "tfft.h")).read()
+    declared = set(re.findall(r"\b(tfft_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    lib = capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.tfft_version()
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(capi.lib_path(), "rb").read()
+    assert b"gfx950" in blob and b"fft4096_kernel" in blob
+
+
+def test_create_plan_matches_reference_arithmetic(orc):
+    for lg in range(8, 30):
+        n = 1 << lg
+        for mode in (tf.Mode_256, tf.Mode_4096):
+            p = tf.CreatePlan(n, mode, 16 if mode == tf.Mode_4096 else 1, 1, 256)
+            o = orc.ref_plan(n, mode)
+            if o is None:
+                assert p is None
+                continue
+            assert (p.amount_of_r16_steps_, p.amount_of_r2_steps_, p.results_in_results_) == o
+            assert p.fft_length_ == n and p.base_fft_mode_ == mode
+            assert p.base_fft_blocksize_ == 32 * p.base_fft_warps_per_block_
+            assert p.base_fft_gridsize_ * p.base_fft_warps_per_block_ == n // 256
+            assert p.base_fft_shared_mem_in_bytes_ == 2048 * p.base_fft_warps_per_block_
+            assert p.r16_shared_mem_in_bytes_ == 1536 * p.r16_warps_per_block_
+
+
+def test_create_plan_defaults_and_overrides(capsys):
+    p = tf.CreatePlan(4096)                       # Mode_256, 8, 8, 256
+    assert (p.base_fft_warps_per_block_, p.base_fft_gridsize_, p.r16_warps_per_block_, p.r2_blocksize_) == (8, 2, 8, 256)
+    assert p.results_in_results_ is False         # one radix-16 pass after the 256 base: lands in the input half
+    p = tf.CreatePlan(256)                        # 1 warp in total: both wpb clamped (Plan.h:119-126,153-160)
+    assert (p.base_fft_warps_per_block_, p.r16_warps_per_block_) == (1, 1)
+    assert "Warning" in capsys.readouterr().out
+    p = tf.CreatePlan(8192, tf.Mode_4096, 8, 8, 256)   # forced to 16 warps (Plan.h:135-141)
+    assert p.base_fft_warps_per_block_ == 16 and p.base_fft_blocksize_ == 512
+
+
+def test_create_plan_rejections(capsys):
+    assert tf.CreatePlan(3000) is None
+    assert "power of 2" in capsys.readouterr().out
+    assert tf.CreatePlan(128) is None
+    assert tf.CreatePlan(1024, tf.Mode_4096) is None
+    assert tf.CreatePlan(1 << 13, tf.Mode_256, 3, 8, 256) is None        # 32 warps not divisible by 3
+    assert tf.CreatePlan(1 << 9, tf.Mode_256, 1, 1, 512) is None         # smallest r2 sub-FFT 256 % 512 != 0
+    rc, _, msg = capi.ref_create_plan(3000)
+    assert rc == 1 and "power of 2" in msg
+
+
+def test_create_plan_from_tuner_file(tmp_path, capsys):
+    f = tmp_path / "TunerResults.dat"
+    f.write_text("4096 4096 16 4 128\n8192 256 8 16 256\n")
+    p = tf.CreatePlan(4096, str(f))
+    assert p.base_fft_mode_ == tf.Mode_4096 and p.r16_warps_per_block_ == 4 and p.r2_blocksize_ == 128
+    p = tf.CreatePlan(8192, str(f))
+    assert p.base_fft_mode_ == tf.Mode_256 and p.r16_warps_per_block_ == 16
+    assert tf.CreatePlan(1 << 20, str(f)) is None
+    assert tf.CreatePlan(4096, str(tmp_path / "missing.dat")) is None
+    assert "tuner file" in capsys.readouterr().out.lower()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "_LIB_NAME", "libtfft_not_built.so")
+    with pytest.raises(ImportError):
+        capi.load_library()
+
+
+def test_no_gpu_means_errors_not_fallbacks():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(tf.TfftError):
+        tf.TfftPlan(4096, 8, 0)
+    with pytest.raises(RuntimeError):
+        tf.DataHandler(4096)
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "tensor-fft_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, fn)

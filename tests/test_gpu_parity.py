@@ -1,0 +1,313 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle. Needs an MI355X: `-m gpu`.
+
+Stated tolerance (fp16 storage, fp16 MFMA operands, fp32 accumulation), against the fp64 DFT(x)/N:
+    rel-L2 error <= 1.5e-3  and  max|delta| <= 1.5 x the max|delta| of the oracle's fp16 restatement
+    of the reference kernels on the same input (+ one fp16 ulp of the largest output),
+and the reference's own acceptance thresholds (UnitTest.cu:14-16) on the reference's test signal.
+Bit-exactness with the CUDA kernels is not defined: they accumulate in fp16 inside HMMA, gfx950 MFMA
+accumulates in fp32.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REL_L2_TOL = 1.5e-3
+AVG_THR, SIGMA_THR, MAX_THR = 1e-3, 1e-2, 0.5      # UnitTest.cu:14-16
+
+
+@pytest.fixture(scope="module")
+def tf():
+    import __graft_entry__ as g
+
+    g.build()
+    import torch
+
+    assert torch.cuda.is_available()
+    import tensor_fft_amd as t
+
+    t.device_check(0)
+    return t
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    return t
+
+
+def _c(re, im):
+    return np.asarray(re, dtype=np.float64) + 1j * np.asarray(im, dtype=np.float64)
+
+
+def _run(tf, torch, re, im, **plan_kw):
+    """re/im: float16 (batch, n) on the host -> float16 (batch, n) pair via tfft_exec, block layout."""
+    batch, n = re.shape
+    host = np.stack([re, im], axis=1)                  # (batch, 2, n) == [fft_i RE | fft_i IM]
+    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda().reshape(-1)
+    out = torch.full_like(dev, float("nan"))
+    plan = tf.TfftPlan(n, batch, 0, **plan_kw)
+    plan.exec(dev, dev[n:], out, out[n:])
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(batch, 2, n)
+    return o[:, 0], o[:, 1]
+
+
+def _check_against_oracle(orc, re, im, got_re, got_im, mode):
+    exact = _c(*orc.dft64(re, im))
+    got = _c(got_re, got_im)
+    assert np.isfinite(got).all()
+    rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+    assert rel <= REL_L2_TOL, rel
+    ref = _c(*orc.ref_fft(re, im, mode))
+    err_got = max(np.abs((got - exact).real).max(), np.abs((got - exact).imag).max())
+    err_ref = max(np.abs((ref - exact).real).max(), np.abs((ref - exact).imag).max())
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(exact).max())) - 10)
+    assert err_got <= 1.5 * err_ref + ulp, (err_got, err_ref)
+    return rel
+
+
+def test_instruction_semantics_probe():
+    exe = os.path.join(ROOT, "tools", "probe_gfx950")
+    if not os.path.exists(exe):
+        subprocess.check_call(["hipcc", "-O2", "--offload-arch=gfx950", "-o", exe, exe + ".hip"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("batch", [1, 8, 37, 300])
+def test_n4096_random_uniform(tf, torch, orc, batch):
+    rng = np.random.default_rng(100 + batch)
+    re = rng.uniform(-1, 1, (batch, 4096)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, 4096)).astype(np.float16)
+    g = _run(tf, torch, re, im)
+    _check_against_oracle(orc, re, im, *g, mode=orc.MODE_4096)
+
+
+def test_n4096_known_answers(tf, torch):
+    n = 4096
+    z = np.zeros((4, n), dtype=np.float16)
+    re = z.copy()
+    im = z.copy()
+    re[0, 0] = 1.0                                   # impulse -> 1/N everywhere
+    re[1, :] = 1.0                                   # constant -> X[0] = 1
+    t = 2 * np.pi * 5 * np.arange(n) / n
+    re[2], im[2] = np.cos(t), np.sin(t)              # exp(+i 2 pi 5 n/N) -> X[5] = 1
+    re[3, 1] = 1.0                                   # shifted impulse -> exp(-2 pi i k/N)/N
+    gr, gi = _run(tf, torch, re, im)
+    np.testing.assert_allclose(gr[0].astype(np.float64), 1.0 / n, rtol=2e-3)
+    assert np.abs(gi[0].astype(np.float64)).max() < 1e-6
+    assert abs(float(gr[1, 0]) - 1.0) < 2e-3 and np.abs(_c(gr[1], gi[1])[1:]).max() < 2e-3
+    assert abs(float(gr[2, 5]) - 1.0) < 3e-3
+    m = np.abs(_c(gr[2], gi[2]))
+    m[5] = 0
+    assert m.max() < 2e-3
+    k = np.arange(n)
+    np.testing.assert_allclose(_c(gr[3], gi[3]), np.exp(-2j * np.pi * k / n) / n, atol=2e-6)
+
+
+def test_n4096_reference_thresholds_on_reference_signal(tf, torch, orc):
+    """UnitTest.cu:8-24: 20 harmonics, seeds 42*i / 42*42*i, thresholds on max/avg/sigma of |delta|."""
+    n = 4096
+    sigs = [orc.sine_superposition(n, orc.random_weights(20, 42 * i), orc.random_weights(20, 42 * 42 * i), 20)
+            for i in range(10)]
+    re = np.stack([s[0] for s in sigs])
+    im = np.stack([s[1] for s in sigs])
+    gr, gi = _run(tf, torch, re, im)
+    ex_re, ex_im = orc.dft64(re, im)
+    for i in range(10):
+        mx, avg, sig = orc.deviation_stats(gr[i].astype(np.float64), gi[i].astype(np.float64), ex_re[i], ex_im[i])
+        assert mx <= MAX_THR and avg <= AVG_THR and sig <= SIGMA_THR
+        assert mx < 1e-3 and avg < 5e-5
+    _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_4096)
+
+
+def test_n4096_golden_benchmark_signal(tf, torch, orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "bench_signal.npz"))
+    re = g["in_re_4096"].view(np.float16)[None, :]
+    im = g["in_im_4096"].view(np.float16)[None, :]
+    gr, gi = _run(tf, torch, re, im)
+    ref = _c(g["ref_re_4096_mode1"].view(np.float16), g["ref_im_4096_mode1"].view(np.float16))
+    # both are within a few fp16 ulps of DFT/N, hence of each other
+    assert np.abs(_c(gr[0], gi[0]) - ref).max() < 1e-3
+    _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_4096)
+
+
+def test_n4096_large_and_tiny_magnitudes(tf, torch, orc):
+    """Per-stage 1/16 scaling keeps |intermediates| <= max|x|: no overflow at fp16 max, and small inputs
+    are not flushed the way an up-front x/4096 (TensorFFT4096.cu:169-173) pushes them into subnormals."""
+    rng = np.random.default_rng(9)
+    base = rng.uniform(-1, 1, (2, 2, 4096))
+    re = np.stack([base[0, 0] * 60000, base[1, 0] * 2e-3]).astype(np.float16)
+    im = np.stack([base[0, 1] * 60000, base[1, 1] * 2e-3]).astype(np.float16)
+    gr, gi = _run(tf, torch, re, im)
+    exact = _c(*orc.dft64(re, im))
+    got = _c(gr, gi)
+    assert np.isfinite(got).all()
+    assert np.linalg.norm(got[0] - exact[0]) / np.linalg.norm(exact[0]) < REL_L2_TOL
+    # row 1: outputs ~3e-5 are fp16-subnormal (quantum 6e-8): absolute bound
+    assert np.abs(got[1] - exact[1]).max() < 2 * 2.0 ** -24 + 1e-3 * np.abs(exact[1]).max()
+
+
+def test_n4096_in_place_and_strides(tf, torch, orc):
+    n, batch = 4096, 19
+    rng = np.random.default_rng(21)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    want = _run(tf, torch, re, im)
+    # (a) in place on the [RE|IM] block
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    plan = tf.TfftPlan(n, batch, 0)
+    plan.exec(dev, dev[n:], dev, dev[n:])
+    torch.cuda.synchronize()
+    o = dev.cpu().numpy().reshape(batch, 2, n)
+    assert np.array_equal(o[:, 0].view(np.uint16), want[0].view(np.uint16))
+    assert np.array_equal(o[:, 1].view(np.uint16), want[1].view(np.uint16))
+    # (b) fully planar: all RE planes, then all IM planes (stride N), padded output stride
+    d_re, d_im = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+    o_re = torch.zeros(batch, n + 64, dtype=torch.float16, device="cuda")
+    o_im = torch.zeros_like(o_re)
+    plan2 = tf.TfftPlan(n, batch, 0, in_batch_stride=n, out_batch_stride=n + 64)
+    plan2.exec(d_re.reshape(-1), d_im.reshape(-1), o_re.reshape(-1), o_im.reshape(-1))
+    torch.cuda.synchronize()
+    assert np.array_equal(o_re[:, :n].cpu().numpy().view(np.uint16), want[0].view(np.uint16))
+    assert np.array_equal(o_im[:, :n].cpu().numpy().view(np.uint16), want[1].view(np.uint16))
+    assert float(o_re[:, n:].abs().max()) == 0.0          # padding untouched
+
+
+def test_n4096_full_size_config(tf, torch, orc):
+    """BASELINE config 2 at full size (batch 65536, 1 GiB in + 1 GiB out): size-independent properties.
+    (1) every wave of every workgroup computes the same thing: one signal replicated over the batch gives
+    bit-identical spectra; (2) Parseval per FFT; (3) linearity spot checks against the oracle on sampled FFTs."""
+    n, batch = 4096, 65536
+    gen = torch.Generator(device="cuda").manual_seed(42)
+    x = (torch.rand(batch, 2, n, device="cuda", generator=gen) * 2 - 1).to(torch.float16)
+    x[1::2] = x[0]                                       # odd FFTs: replicas of FFT 0
+    flat = x.reshape(-1)
+    out = torch.empty_like(flat)
+    plan = tf.TfftPlan(n, batch, 0)
+    plan.exec(flat, flat[n:], out, out[n:])
+    torch.cuda.synchronize()
+    y = out.reshape(batch, 2, n)
+    assert bool((y[1::2] == y[1]).all())
+    e_in = (x.float() ** 2).sum(dim=(1, 2)) / n
+    e_out = (y.float() ** 2).sum(dim=(1, 2))
+    assert float(((e_out - e_in).abs() / e_in).max()) < 5e-3
+    idx = [0, 2, 4094, 32768, 65534, 12346]
+    re = x[idx, 0].cpu().numpy()
+    im = x[idx, 1].cpu().numpy()
+    g = y[idx].cpu().numpy()
+    _check_against_oracle(orc, re, im, g[:, 0], g[:, 1], mode=orc.MODE_4096)
+
+
+@pytest.mark.parametrize("lg", [1, 2, 3, 4, 5, 8, 9, 10, 11, 13, 14, 15, 16])
+def test_generic_lengths(tf, torch, orc, lg):
+    n = 1 << lg
+    batch = 5
+    rng = np.random.default_rng(lg)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    gr, gi = _run(tf, torch, re, im)
+    exact = _c(*orc.dft64(re, im))
+    got = _c(gr, gi)
+    assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL
+    if lg >= 8:
+        _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_256)
+    # preserve_input and in-place variants give the same bits
+    gr2, gi2 = _run(tf, torch, re, im, preserve_input=True)
+    assert np.array_equal(gr2.view(np.uint16), gr.view(np.uint16)) and np.array_equal(gi2.view(np.uint16), gi.view(np.uint16))
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    keep = dev.clone()
+    out = torch.empty_like(dev)
+    tf.TfftPlan(n, batch, 0, preserve_input=True).exec(dev, dev[n:], out, out[n:])
+    torch.cuda.synchronize()
+    assert bool((dev == keep).all())
+    tf.TfftPlan(n, batch, 0).exec(dev, dev[n:], dev, dev[n:])
+    torch.cuda.synchronize()
+    o = dev.cpu().numpy().reshape(batch, 2, n)
+    assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16))
+
+
+def test_n_2pow20(tf, torch, orc):
+    n, batch = 1 << 20, 3
+    rng = np.random.default_rng(20)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    gr, gi = _run(tf, torch, re, im)
+    exact = _c(*orc.dft64(re, im))
+    rel = np.linalg.norm(_c(gr, gi) - exact) / np.linalg.norm(exact)
+    assert rel <= REL_L2_TOL, rel
+
+
+@pytest.mark.parametrize("lg", list(range(8, 21, 2)) + [9, 13])
+def test_reference_api_unit_test_protocol(tf, torch, orc, lg):
+    """The reference's UnitTest.cu flow through its own interface names, both base modes."""
+    n = 1 << lg
+    dev_id = torch.cuda.current_device()
+    for i in (0, 3):
+        w_re, w_im = orc.random_weights(20, 42 * i), orc.random_weights(20, 42 * 42 * i)
+        re, im = orc.sine_superposition(n, w_re, w_im, 20)
+        exact = orc.dft64(re, im)
+        for mode in ((tf.Mode_256,) if n < 4096 else (tf.Mode_256, tf.Mode_4096)):
+            plan = tf.CreatePlan(n, mode, 16 if mode == tf.Mode_4096 else 1, 1, 256)
+            assert plan is not None and tf.PlanWorksOnDevice(plan, dev_id)
+            handler = tf.DataHandler(n)
+            assert handler.PeakAtLastError() is None
+            data = np.concatenate([re, im])
+            assert handler.CopyDataHostToDevice(data) is None
+            assert tf.ComputeFFT(plan, handler, tf.GetMaxNoOptInSharedMem(dev_id)) is None
+            res = np.empty(2 * n, dtype=np.float16)
+            assert handler.CopyResultsDeviceToHost(res, plan.results_in_results_) is None
+            torch.cuda.synchronize()
+            mx, avg, sig = orc.deviation_stats(res[:n].astype(np.float64), res[n:].astype(np.float64), exact[0][0], exact[1][0])
+            assert mx <= MAX_THR and avg <= AVG_THR and sig <= SIGMA_THR, (n, mode, mx, avg, sig)
+            assert mx < 1e-3
+
+
+def test_reference_api_batch_handler(tf, torch, orc):
+    """ExampleBatchFFT.cu / FFTBenchBatch.cu: 20 FFTs through DataBatchHandler, results region layout."""
+    n, b = 4096, 20
+    rng = np.random.default_rng(33)
+    host = rng.uniform(-1, 1, (b, 2, n)).astype(np.float16)
+    plan = tf.CreatePlan(n, tf.Mode_4096, 16, 8, 256)
+    bh = tf.DataBatchHandler(n, b)
+    assert bh.PeakAtLastError() is None
+    assert bh.CopyDataHostToDevice(host.reshape(-1)) is None
+    assert tf.ComputeFFT(plan, bh, 32768) is None
+    res = np.empty(b * 2 * n, dtype=np.float16)
+    assert bh.CopyResultsDeviceToHost(res, plan.results_in_results_) is None
+    res = res.reshape(b, 2, n)
+    _check_against_oracle(orc, host[:, 0], host[:, 1], res[:, 0], res[:, 1], mode=orc.MODE_4096)
+    # per-FFT pointer views address the same memory as the block (DataHandler.h:105-114)
+    assert bh.dptr_results_RE_[3].data_ptr() == bh.dptr_results_RE_[0].data_ptr() + 3 * 2 * n * 2
+    assert bh.dptr_input_IM_[0].data_ptr() == bh.dptr_input_RE_[0].data_ptr() + 2 * n
+
+
+def test_argument_errors(tf, torch):
+    n = 4096
+    plan = tf.TfftPlan(n, 2, 0)
+    buf = torch.zeros(4 * n + 8, dtype=torch.float16, device="cuda")
+    with pytest.raises(tf.TfftError):
+        plan.exec_ptr(buf.data_ptr() + 2, buf.data_ptr() + 2 * n, buf.data_ptr(), buf.data_ptr())   # misaligned
+    with pytest.raises(tf.TfftError):
+        plan.exec_ptr(0, buf.data_ptr(), buf.data_ptr(), buf.data_ptr())                            # null
+    with pytest.raises(tf.TfftError):
+        plan.exec(buf[:n], buf[n:], buf, buf[n:])                                                   # plane too short
+    with pytest.raises(tf.TfftError):
+        tf.TfftPlan(3000, 1, 0)
+    with pytest.raises(tf.TfftError):
+        tf.TfftPlan(4096, 1, 0, in_batch_stride=4100)
+
+
+def test_cxx_shim_example():
+    exe = os.path.join(ROOT, "examples", "example_single_fft")
+    for args in (["12", "5"], ["8", "3"], ["13", "2"], ["16", "2"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        print(r.stdout)
+        assert r.returncode == 0, r.stdout + r.stderr
