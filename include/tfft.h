@@ -94,7 +94,10 @@ typedef struct tfft_plan_opts {
   uint64_t out_batch_stride;
   int preserve_input;   /* 0: the input planes may be used as scratch, exactly as the
                            reference does (ComputeFFT.h:89-93,118-119); 1: never written */
-  int reserved;
+  int variant;          /* tuner knob of the N == 4096 kernel: 0 = default; else a mask of 1 = prefetch the
+                           next transform under stages 2/3, 2 = stage the output through LDS (full-row
+                           stores), 8 = non-temporal loads/stores, 4 = timing-only fake stores (WRONG
+                           results); 16 = none of these */
 } tfft_plan_opts;
 
 int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts,

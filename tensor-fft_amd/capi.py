@@ -52,7 +52,7 @@ class PlanOpts(ctypes.Structure):
         ("in_batch_stride", ctypes.c_uint64),
         ("out_batch_stride", ctypes.c_uint64),
         ("preserve_input", ctypes.c_int),
-        ("reserved", ctypes.c_int),
+        ("variant", ctypes.c_int),
     ]
 
 
@@ -73,6 +73,11 @@ def load_library():
         raise ImportError(
             f"{path} is missing: the HIP extension has not been built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` from the repository root.")
+    # torch first: libtfft.so must bind to the HIP runtime (libamdhip64) that torch has loaded, because
+    # device pointers and streams cross between the two. Loaded the other way round, the process ends up
+    # with two HIP runtimes and the second one sees no device.
+    import torch  # noqa: F401
+
     L = ctypes.CDLL(path)
     vp, u64, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
     L.tfft_ref_create_plan.restype = ci
@@ -132,11 +137,12 @@ def device_check(device_id=0):
 class TfftPlan:
     """Owning wrapper of tfft_plan. exec() takes torch CUDA half tensors (planar)."""
 
-    def __init__(self, n, batch=1, device=0, in_batch_stride=0, out_batch_stride=0, preserve_input=False):
+    def __init__(self, n, batch=1, device=0, in_batch_stride=0, out_batch_stride=0, preserve_input=False,
+                 variant=0):
         L = load_library()
         self._lib = L
         self._h = ctypes.c_void_p()
-        opts = PlanOpts(int(in_batch_stride), int(out_batch_stride), int(bool(preserve_input)), 0)
+        opts = PlanOpts(int(in_batch_stride), int(out_batch_stride), int(bool(preserve_input)), int(variant))
         _check(L.tfft_plan_create(int(n), int(batch), int(device), ctypes.byref(opts), ctypes.byref(self._h)))
         self.n, self.batch, self.device = int(n), int(batch), int(device)
         self.in_batch_stride = int(in_batch_stride) or 2 * self.n
@@ -144,9 +150,10 @@ class TfftPlan:
         self._ws = None
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h:
-            self._lib.tfft_plan_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        h = getattr(self, "_h", None)
+        if h:
+            self._h = None
+            self._lib.tfft_plan_destroy(h)
 
     __del__ = close
 

@@ -165,10 +165,69 @@ __device__ __forceinline__ f4 mfma(h8 a, h8 b) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, z, 0, 0, 0);
 }
 
+// Kernel variants (tuner knob, see tfft_plan_opts::variant):
+//   kPrefetch   issue the next transform's HBM->LDS copy as soon as stage 1 has read the
+//               current one out of LDS, so it flies under stages 2/3 and the stores.
+//   kStageOut   stage the spectrum through the wave's LDS region and store it as
+//               full 1-KiB rows (mutually exclusive with kPrefetch: same LDS bytes).
+//   kFakeStore  timing experiment only (WRONG output): coalesced stores of the raw registers.
+//   kNonTemporal  nt cache policy on the streamed loads and stores (every byte is touched once).
+enum : int { kPrefetch = 1, kStageOut = 2, kFakeStore = 4, kNonTemporal = 8 };
+
+// LDS-DMA of one transform: 16 x global_load_lds_dwordx4 hidden from the compiler's
+// wait-count bookkeeping (inline asm), so that the only waits are the counted ones below.
+template <bool NT>
+__device__ __forceinline__ void dma_in(const uint8_t* src_re, const uint8_t* src_im, uint32_t lds_off, int lane) {
+  // block mm of a plane = rows n2 = 2mm, 2mm+1 = 64 chunks of 16 B; LDS slot l of the block
+  // receives global chunk l ^ 2mm (swizzle applied on the source address).
+#pragma unroll
+  for (int mm = 0; mm < 8; ++mm) {
+    const uint32_t chunk = static_cast<uint32_t>(mm * 64 + (lane ^ (2 * mm))) * 16u;
+    const uint8_t* gr = src_re + chunk;
+    const uint8_t* gi = src_im + chunk;
+    const uint32_t d0 = lds_off + mm * 1024, d1 = lds_off + 8192 + mm * 1024;
+    uint32_t keep;
+    if (NT)
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off nt\n\t"
+          "s_mov_b32 m0, %4\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %2, off nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+          : "memory");
+    else
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %4\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %2, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+          : "memory");
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void st(uint16_t* p, u4 v) {
+  if (V & kNonTemporal)
+    __builtin_nontemporal_store(v, reinterpret_cast<u4*>(p));
+  else
+    *reinterpret_cast<u4*>(p) = v;
+}
+
 // in_*/out_*: planar binary16; FFT b at +b*stride halves. tables: build_tables() blob.
+template <int V>
 __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
-    const uint16_t* in_re, const uint16_t* in_im,
-    uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
+    const uint16_t* in_re, const uint16_t* in_im, uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
     uint64_t out_stride, uint32_t batch, const uint8_t* __restrict__ tables) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -183,9 +242,13 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
   const h8 f_im = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32 + 16);
   const f4 tw_re = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
   const f4 tw_im = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // table loads retired: vmcnt below counts only loop traffic
   __syncthreads();
 
   uint8_t* const wl = lds + kLdsTableBytes + wave * kLdsWaveBytes;
+  // LDS byte address of this wave's region (M0 base of its LDS-DMA)
+  const uint32_t wl_off = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)wl)));
   const uint8_t* const g_tab = lds + lane * 16;
   const uint8_t* const h_tab = lds + 16384 + lane * 16;
 
@@ -198,20 +261,21 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
   // output geometry: lane (k1 = lane & 15, g) owns k2 = 4 g + r, k0 = 0..15
   const uint32_t out_lane_off = 16u * (lane & 15) + 1024u * g;   // halves, + 256 r + k0
 
-  for (uint32_t b = blockIdx.x * kWavesPerBlock + wave; b < batch;
-       b += gridDim.x * kWavesPerBlock) {
-    const uint8_t* src_re = reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(b) * in_stride);
-    const uint8_t* src_im = reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(b) * in_stride);
+  const uint32_t stride_b = gridDim.x * kWavesPerBlock;
+  uint32_t b = blockIdx.x * kWavesPerBlock + wave;
+  if (b >= batch) return;
+  dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(b) * in_stride),
+         reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(b) * in_stride), wl_off, lane);
+  bool first = true;
 
-    // ---- HBM -> LDS: block mm of a plane = rows n2 = 2mm, 2mm+1 = 64 chunks of 16 B;
-    // LDS slot l of the block receives global chunk l ^ 2mm (swizzle on the source).
-#pragma unroll
-    for (int mm = 0; mm < 8; ++mm) {
-      const uint32_t chunk = static_cast<uint32_t>(mm * 64 + (lane ^ (2 * mm))) * 16u;
-      __builtin_amdgcn_global_load_lds(TFFT_GLB(src_re + chunk), TFFT_LDS(wl + mm * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(TFFT_GLB(src_im + chunk), TFFT_LDS(wl + 8192 + mm * 1024), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (; b < batch; b += stride_b) {
+    // The 16 copies of this transform are the oldest outstanding vector-memory operations; with
+    // prefetch the previous iteration issued its 16 output stores after them, and vmcnt retires in order.
+    if ((V & kPrefetch) && !first)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    first = false;
 
     // ---- stage 1: D1_n1[k0 = 4g + r][n0 = lane & 15], packed over tile pairs
     uint32_t pr[8][4], pi[8][4];   // [t = n1 >> 1][r]: lo half n1 = 2t, hi half n1 = 2t + 1
@@ -239,6 +303,16 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       }
     }
 
+    const uint32_t nb = b + stride_b;
+    if (V & kPrefetch) {
+      // every transposed read above has returned (its data fed an MFMA whose result is consumed
+      // below, but make it explicit) before the region is overwritten by the next transform
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (nb < batch)
+        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(nb) * in_stride),
+               reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(nb) * in_stride), wl_off, lane);
+    }
+
     // ---- n1 high bits (register index a = t >> 1) <-> k0 high bits (lane group)
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
@@ -249,8 +323,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       }
     // now pr[2a + pp][r] holds, for tile k0 = 4a + r, slots n1 = 4g + 2pp + {0,1}.
 
-    uint16_t* dst_re = out_re + static_cast<uint64_t>(b) * out_stride + out_lane_off;
-    uint16_t* dst_im = out_im + static_cast<uint64_t>(b) * out_stride + out_lane_off;
+    uint16_t* const fft_re = out_re + static_cast<uint64_t>(b) * out_stride;
+    uint16_t* const fft_im = out_im + static_cast<uint64_t>(b) * out_stride;
 
     // ---- stages 2 and 3, tile by tile; 8 tiles fill one 16-byte output vector
     auto tile23 = [&](int k0, f4& o_re, f4& o_im) {
@@ -288,9 +362,39 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       for (int r2 = 0; r2 < 4; ++r2) {
         const u4 vr = {ore[r2][0], ore[r2][1], ore[r2][2], ore[r2][3]};
         const u4 vi = {oim[r2][0], oim[r2][1], oim[r2][2], oim[r2][3]};
-        *reinterpret_cast<u4*>(dst_re + 256 * r2 + 8 * half) = vr;
-        *reinterpret_cast<u4*>(dst_im + 256 * r2 + 8 * half) = vi;
+        if (V & kFakeStore) {
+          st<V>(fft_re + 8 * lane + 512 * (2 * r2 + half), vr);
+          st<V>(fft_im + 8 * lane + 512 * (2 * r2 + half), vi);
+        } else if (V & kStageOut) {
+          // byte offset of this piece in the [RE 8 KiB | IM 8 KiB] image: 32 k1 + 16 half + 512 (4g + r2);
+          // the 16-byte slot index (2 k1 + half) is XORed with bit 3 of itself so that lanes k1 and
+          // k1 + 4 of one store group hit different banks.
+          const uint32_t slot = 2u * (lane & 15) + half;
+          const uint32_t off = 16u * (slot ^ ((slot >> 3) & 1)) + 512u * (4 * g + r2);
+          *reinterpret_cast<u4*>(wl + off) = vr;
+          *reinterpret_cast<u4*>(wl + 8192 + off) = vi;
+        } else {
+          st<V>(fft_re + out_lane_off + 256 * r2 + 8 * half, vr);
+          st<V>(fft_im + out_lane_off + 256 * r2 + 8 * half, vi);
+        }
       }
+    }
+    if (V & kStageOut) {
+      // read the image back row by row (1 KiB per wave instruction) and store it coalesced
+      const uint32_t rd = 16u * (lane ^ ((lane >> 3) & 1));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u4 vr = *reinterpret_cast<const u4*>(wl + 1024 * i + rd);
+        const u4 vi = *reinterpret_cast<const u4*>(wl + 8192 + 1024 * i + rd);
+        st<V>(fft_re + 512 * i + 8 * lane, vr);
+        st<V>(fft_im + 512 * i + 8 * lane, vi);
+      }
+    }
+    if (!(V & kPrefetch)) {
+      if (V & kStageOut) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image read out before reuse
+      if (nb < batch)
+        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(nb) * in_stride),
+               reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(nb) * in_stride), wl_off, lane);
     }
   }
 }

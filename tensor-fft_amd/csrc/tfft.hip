@@ -58,6 +58,7 @@ struct tfft_plan {
   bool preserve_input = false;
   Kind kind = Kind::Stockham;
   int num_cus = 0;
+  int variant = 0;
   // K4096
   void* d_tables = nullptr;
   // Stockham
@@ -73,18 +74,45 @@ struct tfft_plan {
 
 namespace {
 
-int launch_k4096(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                 hipStream_t s) {
+template <int V>
+int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                   hipStream_t s) {
+  static std::once_flag once[16];   // per device: opt in to the full 160 KiB of LDS
+  hipError_t attr = hipSuccess;
+  std::call_once(once[p->device & 15], [&] {
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k4096::fft4096_kernel<V>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, k4096::kLdsBytes);
+  });
+  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint32_t blocks_needed =
       static_cast<uint32_t>((p->batch + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
   const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
-  hipLaunchKernelGGL(k4096::fft4096_kernel, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+  hipLaunchKernelGGL(k4096::fft4096_kernel<V>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), p->in_stride,
                      p->out_stride, static_cast<uint32_t>(p->batch),
                      static_cast<const uint8_t*>(p->d_tables));
   TFFT_HIP(hipGetLastError());
   return TFFT_OK;
+}
+
+int launch_k4096(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                 hipStream_t s) {
+  // opts.variant: 0 = default (staged, coalesced, non-temporal stores: the fastest measured on MI355X);
+  // otherwise a mask of k4096::kPrefetch / kStageOut / kFakeStore / kNonTemporal, with 16 = "none of them".
+  const int v = p->variant == 0 ? (k4096::kStageOut | k4096::kNonTemporal) : (p->variant & 15);
+  switch (v) {
+    case 0: return launch_k4096_v<0>(p, in_re, in_im, out_re, out_im, s);
+    case 1: return launch_k4096_v<1>(p, in_re, in_im, out_re, out_im, s);
+    case 2: return launch_k4096_v<2>(p, in_re, in_im, out_re, out_im, s);
+    case 4: return launch_k4096_v<4>(p, in_re, in_im, out_re, out_im, s);
+    case 5: return launch_k4096_v<5>(p, in_re, in_im, out_re, out_im, s);
+    case 8: return launch_k4096_v<8>(p, in_re, in_im, out_re, out_im, s);
+    case 9: return launch_k4096_v<9>(p, in_re, in_im, out_re, out_im, s);
+    case 10: return launch_k4096_v<10>(p, in_re, in_im, out_re, out_im, s);
+    case 13: return launch_k4096_v<13>(p, in_re, in_im, out_re, out_im, s);
+    default: return fail(TFFT_ERR_ARG, "unknown kernel variant");
+  }
 }
 
 template <int R>
@@ -277,6 +305,7 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
   p->in_stride = in_stride;
   p->out_stride = out_stride;
   p->preserve_input = opts && opts->preserve_input;
+  p->variant = opts ? opts->variant : 0;
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device_id);
   p->num_cus = (e == hipSuccess) ? prop.multiProcessorCount : 256;
@@ -293,9 +322,6 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(tables)"));
     e = hipMemcpy(p->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tables)"));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4096::fft4096_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, k4096::kLdsBytes);
-    if (e != hipSuccess) return bail(hip_fail(e, "hipFuncSetAttribute(LDS)"));
   } else {
     p->kind = Kind::Stockham;
     const int lg = ilog2(n);

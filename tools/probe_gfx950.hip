@@ -32,13 +32,17 @@ __global__ void probe(const _Float16* A, const _Float16* B, float* D, const _Flo
   for (int j = 0; j < 8; ++j) dma_out[8 * l + j] = lds[8 * l + j];
   __syncthreads();
   // 3. tr read: LDS = 64 rows x 16 halfs, value = 16*row + col. lane = 16g+4q+p supplies row 4g+q, cols 4p..
-  for (int i = l; i < 1024; i += 64) lds[i] = (_Float16)(float)i;
-  __syncthreads();
   {
+    volatile unsigned short* l16 = reinterpret_cast<volatile unsigned short*>(lds);
+    for (int i = l; i < 1024; i += 64) l16[i] = __builtin_bit_cast(unsigned short, (_Float16)(float)i);
+    __syncthreads();
     const int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
     const s4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (__attribute__((address_space(3))) s4*)(lds + 16 * (4 * g + q) + 4 * p));
-    for (int j = 0; j < 4; ++j) tr_out[4 * l + j] = __builtin_bit_cast(_Float16, t[j]);
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    const u2_t raw = __builtin_bit_cast(u2_t, t);
+    reinterpret_cast<unsigned*>(tr_out)[2 * l] = raw.x;
+    reinterpret_cast<unsigned*>(tr_out)[2 * l + 1] = raw.y;
   }
   // 4. permlane swaps
   unsigned x = l, y = 100 + l;
