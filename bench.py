@@ -44,8 +44,7 @@ def cpu_baseline(seconds_target=12.0):
     t0 = time.perf_counter()
     orc.dft64(re, im)
     rate = probe / (time.perf_counter() - t0)                    # FFTs / s
-    count = int(max(probe, min(BATCH, rate * seconds_target)))
-    reps = -(-count // probe)
+    reps = max(1, int(rate * seconds_target / probe))           # bounded: about seconds_target of CPU work
     t0 = time.perf_counter()
     for _ in range(reps):
         orc.dft64(re, im)
@@ -56,8 +55,25 @@ def cpu_baseline(seconds_target=12.0):
         "unit": "Gsamples/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{done} of {BATCH} FFTs (N={N}), oracle fp64 radix-2 FFT/N, OpenMP over the batch, {dt:.1f} s",
+        "sample": f"{done} FFTs of N={N} ({done / BATCH:.2f} x the GPU batch of {BATCH}; the same {probe} random "
+                  f"transforms repeated), oracle fp64 radix-2 FFT/N, OpenMP over the batch, {dt:.1f} s",
     }
+
+
+def measured_traffic(kernel_name):
+    """HBM bytes per launch from the newest committed PMC summary (tools/summarize_pmc.py; FETCH_SIZE x2 +
+    WRITE_SIZE from separate rocprofv3 --pmc passes of this same command), or None."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel") == kernel_name and "hbm_bytes_per_dispatch" in d:
+            best = (d["hbm_bytes_per_dispatch"]["total"], os.path.relpath(path, ROOT))
+    return best
 
 
 def main():
@@ -138,6 +154,7 @@ def main():
         alg_bytes = plan.algorithmic_bytes                      # per launch, this rank
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         mfma_tflops = plan.mfma_flops / (kernel_ms * 1e-3) / 1e12
+        traffic = measured_traffic(plan.kernel_name) if batch == BATCH else None
         line = {
             "metric": "Gsamples/s + %fp16-MFMA-peak, batched N=4096 fp16 C2C FFT",
             "value": value,
@@ -165,7 +182,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic[0] if traffic else None,
+                "traffic_source": traffic[1] if traffic else None,
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
