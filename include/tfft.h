@@ -86,18 +86,21 @@ int tfft_max_no_optin_shared_mem(int device_id);
 /* Execution plan for `batch` transforms of length n on `device_id`.
  * n: power of two >= 2 (the reference-compatible shim enforces >= 256).
  * in/out_batch_stride: distance in halves between consecutive FFTs of a plane;
- * 0 selects the DataBatchHandler default 2*n. Must be a multiple of 8.
+ * 0 selects the DataBatchHandler default 2*n (2*n*inner). Must be a multiple of 8.
  * The plan is immutable after creation and may be shared between host threads;
  * it owns small device-side constant tables (and a workspace if it allocated one). */
 typedef struct tfft_plan_opts {
   uint64_t in_batch_stride;
   uint64_t out_batch_stride;
+  uint64_t inner;       /* 0/1: plain batched transforms. C >= 8 (power of two): transform along a strided
+                           axis, data [batch][n][C] with C independent columns innermost (2D column pass,
+                           local passes of a distributed transform) */
   int preserve_input;   /* 0: the input planes may be used as scratch, exactly as the
                            reference does (ComputeFFT.h:89-93,118-119); 1: never written */
   int variant;          /* tuner knob of the N == 4096 kernel: 0 = default; else a mask of 1 = prefetch the
                            next transform under stages 2/3, 2 = stage the output through LDS (full-row
                            stores), 8 = non-temporal loads/stores, 4 = timing-only fake stores (WRONG
-                           results); 16 = none of these */
+                           results); 16 = none of these; 32 = (any N) plain autosort chain, no column kernel */
 } tfft_plan_opts;
 
 int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts,

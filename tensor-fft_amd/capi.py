@@ -51,6 +51,7 @@ class PlanOpts(ctypes.Structure):
     _fields_ = [
         ("in_batch_stride", ctypes.c_uint64),
         ("out_batch_stride", ctypes.c_uint64),
+        ("inner", ctypes.c_uint64),
         ("preserve_input", ctypes.c_int),
         ("variant", ctypes.c_int),
     ]
@@ -138,15 +139,15 @@ class TfftPlan:
     """Owning wrapper of tfft_plan. exec() takes torch CUDA half tensors (planar)."""
 
     def __init__(self, n, batch=1, device=0, in_batch_stride=0, out_batch_stride=0, preserve_input=False,
-                 variant=0):
+                 variant=0, inner=1):
         L = load_library()
         self._lib = L
         self._h = ctypes.c_void_p()
-        opts = PlanOpts(int(in_batch_stride), int(out_batch_stride), int(bool(preserve_input)), int(variant))
+        opts = PlanOpts(int(in_batch_stride), int(out_batch_stride), int(inner), int(bool(preserve_input)), int(variant))
         _check(L.tfft_plan_create(int(n), int(batch), int(device), ctypes.byref(opts), ctypes.byref(self._h)))
-        self.n, self.batch, self.device = int(n), int(batch), int(device)
-        self.in_batch_stride = int(in_batch_stride) or 2 * self.n
-        self.out_batch_stride = int(out_batch_stride) or 2 * self.n
+        self.n, self.batch, self.device, self.inner = int(n), int(batch), int(device), int(inner)
+        self.in_batch_stride = int(in_batch_stride) or 2 * self.n * self.inner
+        self.out_batch_stride = int(out_batch_stride) or 2 * self.n * self.inner
         self._ws = None
 
     def close(self):
@@ -193,8 +194,8 @@ class TfftPlan:
                 raise TfftError(5, "planes must be contiguous CUDA float16 tensors")
             if t.device.index != self.device:
                 raise TfftError(5, "tensor on another device than the plan")
-        need_in = (self.batch - 1) * self.in_batch_stride + self.n
-        need_out = (self.batch - 1) * self.out_batch_stride + self.n
+        need_in = (self.batch - 1) * self.in_batch_stride + self.n * self.inner
+        need_out = (self.batch - 1) * self.out_batch_stride + self.n * self.inner
         if in_re.numel() < need_in or in_im.numel() < need_in or out_re.numel() < need_out or out_im.numel() < need_out:
             raise TfftError(5, "a plane is shorter than (batch-1)*stride + N")
         if stream is None:

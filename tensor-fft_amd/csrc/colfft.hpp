@@ -1,0 +1,245 @@
+// colfft.hpp — 256-point FFT along a strided axis, 16 adjacent columns per wave (gfx950).
+//
+// The building block for everything longer than 4096 and for FFTs along a non-contiguous axis
+// (2D column pass, local passes of the distributed transform). It plays the role of the reference's
+// TensorRadix16 pass (src/base/TensorRadix16.cu:36-214: one L -> 16 L combine per launch, 32-byte
+// global segments) but covers a radix-256 step per launch and keeps the autosort ("Stockham")
+// indexing of stockham.hpp so the two kinds of pass can be chained:
+//
+//   input   x[i * pitch + m]      i = 0..255 (the digit being transformed), m = flattened column
+//   output  y[rest * 256 Ns + k * Ns + kprev]   with m = rest * Ns + kprev   (Ns = "ns_f")
+//   Ns == 1 (first pass of a plain 1D transform): y[m * 256 + k], each column's spectrum contiguous.
+//
+// If another pass follows, the twiddle that pass needs on its input, w_T^(a (kprev' + Ns' k)), is
+// applied here to the fp32 accumulators (per lane: five table look-ups and a 16-step recurrence), so
+// the next pass reads plain data.
+//
+// Machine mapping = stages 1 and 2 of k4096.hpp with the column index in the place of n0:
+//   i = i_lo + 16 i_hi; stage 1 contracts i_hi (transposed LDS reads, F as the A operand), the
+//   4x4 permlane transposes move i_lo's high bits next to the lanes, stage 2 contracts i_lo against
+//   the same G_ka tables (twiddle w256^(i_lo ka) folded in). k = ka + 16 kb.
+//   Mode kColsOnLanes  (Ns == 1): stage 2 with the data as B operand: lane = column, each lane
+//                      ends up with 64 consecutive k -> 128-byte runs per lane.
+//   Mode kColsInRegs   (Ns >= 16): data as A operand: lane = kb, registers = 4 adjacent columns
+//                      -> 8-byte pieces, 32-byte runs per lane group, rows k at stride Ns.
+#pragma once
+
+#include "k4096.hpp"
+
+namespace colfft {
+
+using namespace k4096;
+
+constexpr int kLdsTable = 16384;                                   // G only
+constexpr int kLdsBytes = kLdsTable + kWavesPerBlock * kLdsWaveBytes;   // 144 KiB
+
+enum : int { kColsOnLanes = 0, kColsInRegs = 1 };
+
+struct Args {
+  const uint16_t* in_re;
+  const uint16_t* in_im;
+  uint16_t* out_re;
+  uint16_t* out_im;
+  uint64_t in_stride, out_stride;   // halves between the (outer) batch entries
+  uint64_t pitch;                   // halves between consecutive i (= number of flattened columns)
+  uint64_t ns_f;                    // flattened Ns (a power of two: 1, or a multiple of 16)
+  uint32_t ns_f_shift;              // log2(ns_f)
+  uint32_t groups;                  // column groups of 16 per batch entry = pitch / 16
+  uint32_t tasks;                   // groups * batch
+  // twiddle for the next pass (unused when !TW): E = a * (kprev + ns * k) mod T, looked up in w_N tables
+  uint32_t inner_shift;             // log2 C: flattened column = column * C + c
+  uint32_t a_shift;                 // a = rest >> a_shift        (rest = m >> ns_f_shift)
+  uint64_t ns;                      // unflattened Ns of THIS pass = ns_f / C
+  uint64_t t_mask;                  // T - 1
+  uint64_t n_over_t;                // N / T : exponent scale into the w_N tables
+  uint64_t n_mask;                  // N - 1
+  const float2* tw_lo;
+  const float2* tw_hi;
+  const uint8_t* tables;            // k4096::build_tables blob
+};
+
+struct cpx {
+  float re, im;
+};
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+
+__device__ __forceinline__ cpx lookup(const Args& a, uint64_t e_t) {   // w_T^(e_t), e_t already reduced mod T
+  const uint64_t e = (e_t * a.n_over_t) & a.n_mask;
+  const float2 lo = a.tw_lo[e & 8191];
+  cpx w = {lo.x, lo.y};
+  if (a.n_mask >= 8192) {
+    const float2 hi = a.tw_hi[e >> 13];
+    w = cmul(w, cpx{hi.x, hi.y});
+  }
+  return w;
+}
+
+template <int MODE, bool TW>
+__global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < kLdsTable / 16; i += kThreads)
+    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(a.tables + kOffG)[i];
+  const h8 f_re = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32);
+  const h8 f_im = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32 + 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  uint8_t* const wl = lds + kLdsTable + wave * kLdsWaveBytes;
+  const uint32_t wl_off = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)wl)));
+  const uint8_t* const g_tab = lds + lane * 16;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, x = lane & 15;
+  // LDS image of a plane: 16-byte slot (i_lo * 16 + i_hi) * 2 + h holds columns 8h..8h+7 of row i_lo + 16 i_hi.
+  // transposed read of tile i_lo: lane 16g + 4q + p supplies row i_hi = 4g + q, columns 4p..4p+3.
+  const uint8_t* const tr_base = wl + (4 * g + q) * 32 + 8 * p;
+  // copy-in geometry: instruction i, lane l: h = l & 1, i_hi = (l >> 1) & 15, i_lo = 2 i + (l >> 5)
+  const uint64_t in_lane_off = (static_cast<uint64_t>(16 * ((lane >> 1) & 15) + (lane >> 5)) * a.pitch + 8 * (lane & 1)) * 2;
+
+  for (uint32_t task = blockIdx.x * kWavesPerBlock + wave; task < a.tasks; task += gridDim.x * kWavesPerBlock) {
+    const uint32_t bidx = task / a.groups;
+    const uint64_t m0 = static_cast<uint64_t>(task - bidx * a.groups) * 16;
+    const uint8_t* src_re = reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride + m0) + in_lane_off;
+    const uint8_t* src_im = reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride + m0) + in_lane_off;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint8_t* gr = src_re + static_cast<uint64_t>(2 * i) * a.pitch * 2;
+      const uint8_t* gi = src_im + static_cast<uint64_t>(2 * i) * a.pitch * 2;
+      const uint32_t d0 = wl_off + i * 1024, d1 = wl_off + 8192 + i * 1024;
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %4\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %2, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+          : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- stage 1: D1_ilo[ka = 4g + r][column = lane & 15]
+    uint32_t pr[8][4], pi[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f4 dre[2], dim[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint8_t* ad = tr_base + (2 * t + e) * 512;
+        const s4 xr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad));
+        const s4 xi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad + 8192));
+        const u4 raw = {__builtin_bit_cast(u2, xr).x, __builtin_bit_cast(u2, xr).y,
+                        __builtin_bit_cast(u2, xi).x, __builtin_bit_cast(u2, xi).y};
+        const h8 xv = __builtin_bit_cast(h8, raw);
+        dre[e] = mfma(f_re, xv);
+        dim[e] = mfma(f_im, xv);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[t][r] = pk(dre[0][r], dre[1][r]);
+        pi[t][r] = pk(dim[0][r], dim[1][r]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image consumed: the next task may overwrite it
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        transpose4(pr[0 + pp][r], pr[2 + pp][r], pr[4 + pp][r], pr[6 + pp][r]);
+        transpose4(pi[0 + pp][r], pi[2 + pp][r], pi[4 + pp][r], pi[6 + pp][r]);
+      }
+
+    // ---- twiddle set-up: tw(col, k) = base_r * step^ka with k = ka + 16 kb,
+    //      exponent E = a (kprev + ns k) mod T, a and kprev functions of the column
+    const uint64_t rest = m0 >> a.ns_f_shift;
+    const uint64_t kprev_f0 = m0 - (rest << a.ns_f_shift);
+    cpx base[4], step = {1.f, 0.f};
+    if (TW) {
+      const uint64_t rest_l = (MODE == kColsOnLanes) ? ((m0 + x) >> a.ns_f_shift) : rest;   // this lane's column
+      const uint64_t av = rest_l >> a.a_shift;
+      step = lookup(a, (av * (a.ns & a.t_mask)) & a.t_mask);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t kb = (MODE == kColsOnLanes) ? (4 * g + r) : x;
+        const uint64_t kprev = (MODE == kColsOnLanes)
+                                   ? (((m0 + x) - (rest_l << a.ns_f_shift)) >> a.inner_shift)
+                                   : ((kprev_f0 + 4 * g + r) >> a.inner_shift);
+        base[r] = lookup(a, (av * ((kprev + a.ns * 16 * kb) & a.t_mask)) & a.t_mask);
+      }
+    }
+
+    uint16_t* const o_re = a.out_re + bidx * a.out_stride;
+    uint16_t* const o_im = a.out_im + bidx * a.out_stride;
+    cpx pw = {1.f, 0.f};                                   // step^ka, advanced tile by tile
+    float hold_re[4], hold_im[4];                          // kColsOnLanes: even tile waiting for its odd partner
+    uint32_t acc_re[4][4], acc_im[4][4];                   // kColsOnLanes: [r][pair within half]
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) {
+      const int aa = ka >> 2, r0 = ka & 3;
+      const u4 draw = {pr[2 * aa][r0], pr[2 * aa + 1][r0], pi[2 * aa][r0], pi[2 * aa + 1][r0]};
+      const h8 dop = __builtin_bit_cast(h8, draw);
+      const u4 graw = *reinterpret_cast<const u4*>(g_tab + ka * 1024);
+      f4 e_re, e_im;
+      if (MODE == kColsOnLanes) {      // rows kb = 4g + r, column on the lane
+        e_re = mfma(__builtin_bit_cast(h8, graw), dop);
+        e_im = mfma(im_form(graw), dop);
+      } else {                         // rows = columns 4g + r, kb on the lane
+        e_re = mfma(dop, __builtin_bit_cast(h8, graw));
+        e_im = mfma(dop, im_form(graw));
+      }
+      if (TW) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const cpx w = cmul(base[r], pw);
+          const float vr = e_re[r] * w.re - e_im[r] * w.im;
+          const float vi = e_re[r] * w.im + e_im[r] * w.re;
+          e_re[r] = vr;
+          e_im[r] = vi;
+        }
+        pw = cmul(pw, step);
+      }
+      if (MODE == kColsInRegs) {
+        // 4 adjacent columns 4g..4g+3 of row k = ka + 16 kb: one 8-byte store per plane
+        const uint64_t o = ((rest << 8) << a.ns_f_shift) + (static_cast<uint64_t>(ka + 16 * x) << a.ns_f_shift) + kprev_f0 + 4 * g;
+        const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
+        const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
+        *reinterpret_cast<u2*>(o_re + o) = vr;
+        *reinterpret_cast<u2*>(o_im + o) = vi;
+      } else {
+        if ((ka & 1) == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            hold_re[r] = e_re[r];   // (no __builtin_bit_cast on a vector element: clang reads element 0)
+            hold_im[r] = e_im[r];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc_re[r][(ka >> 1) & 3] = pk(hold_re[r], e_re[r]);
+            acc_im[r][(ka >> 1) & 3] = pk(hold_im[r], e_im[r]);
+          }
+          if ((ka & 7) == 7) {
+            // k = 16 (4g + r) + 8 half .. + 7 of column m0 + x: 16 bytes per plane
+            const int half = ka >> 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const uint64_t o = (m0 + x) * 256 + 16 * (4 * g + r) + 8 * half;
+              const u4 vr = {acc_re[r][0], acc_re[r][1], acc_re[r][2], acc_re[r][3]};
+              const u4 vi = {acc_im[r][0], acc_im[r][1], acc_im[r][2], acc_im[r][3]};
+              *reinterpret_cast<u4*>(o_re + o) = vr;
+              *reinterpret_cast<u4*>(o_im + o) = vi;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace colfft

@@ -63,7 +63,8 @@ constexpr int kOffF1 = 0;        // 64 lanes x {RE-form 8 halfs, IM-form 8 halfs
 constexpr int kOffTw = 2048;     // 64 lanes x {float re[4], float im[4]}
 constexpr int kOffG = 4096;      // 16 tiles x 64 lanes x 8 halfs (RE-form)
 constexpr int kOffH = kOffG + 16384;
-constexpr int kTableBytes = kOffH + 16384;
+constexpr int kOffF1n = kOffH + 16384;   // as kOffF1 but slots in natural order (column-pass kernel)
+constexpr int kTableBytes = kOffF1n + 2048;
 
 // Contraction slot (lane group g, j) of stage 1 holds n2 = sigma(g, j): even rows
 // for lanes 0-31, odd rows for lanes 32-63, so that each 32-lane half of a
@@ -108,6 +109,17 @@ inline void build_tables(std::vector<uint8_t>& blob) {
       put_h(base + 2 * j, c);              // RE-form  [ C_re | -C_im ]
       put_h(base + 2 * (4 + j), -s);
       put_h(base + 16 + 2 * j, s);         // IM-form  [ C_im |  C_re ]
+      put_h(base + 16 + 2 * (4 + j), c);
+    }
+    for (int j = 0; j < 4; ++j) {          // natural slot order: contraction index 4g + j
+      double c, s;
+      cexp(static_cast<long>(4 * g + j) * x, 16, c, s);
+      c /= 16.0;
+      s /= 16.0;
+      const int base = kOffF1n + lane * 32;
+      put_h(base + 2 * j, c);
+      put_h(base + 2 * (4 + j), -s);
+      put_h(base + 16 + 2 * j, s);
       put_h(base + 16 + 2 * (4 + j), c);
     }
     // elementwise twiddle w256^(n0 k1), n0 = 4 g + r, k1 = x

@@ -17,6 +17,8 @@
 //   j in [0, N/R):  k = j mod Ns
 //   v[i] = x[j + i N/R] * w_{Ns R}^(i k),  i = 0..R-1
 //   y[(j - k) R + k + i Ns] = DFT_R(v)[i] / R
+// With an inner batch C (transform along a strided axis) every index above is flattened with c
+// (j -> j C + c, Ns -> Ns C); only the twiddle uses the unflattened k.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -121,8 +123,11 @@ struct PassArgs {
   _Float16* out_im;
   uint64_t in_stride;    // halves between FFTs
   uint64_t out_stride;
-  uint64_t n;            // FFT length
-  uint64_t ns;           // sub-transform length before this pass
+  uint64_t n;            // FFT length (twiddle table modulus)
+  uint64_t m_f;          // flattened butterflies per transform = (n / R) * inner
+  uint64_t ns;           // flattened sub-transform length before this pass = Ns * inner
+  uint32_t inner_shift;  // log2(inner): flattened index = index * inner + c (FFT along a strided axis)
+  uint32_t skip_tw;      // the previous pass already applied this pass's input twiddles
   uint64_t tw_mul;       // N / (Ns * R): exponent of w_N per unit of i*k
   uint64_t blocks_per_fft;
   const float2* tw_lo;   // w_N^e, e < min(N, 8192)
@@ -133,16 +138,16 @@ template <int R>
 __global__ __launch_bounds__(kBlock) void pass_kernel(PassArgs a) {
   const uint64_t fft = blockIdx.x / a.blocks_per_fft;
   const uint64_t j = (blockIdx.x % a.blocks_per_fft) * kBlock + threadIdx.x;
-  const uint64_t m = a.n / R;
+  const uint64_t m = a.m_f;
   if (j >= m) return;
-  const uint64_t k = j & (a.ns - 1);
+  const uint64_t k = j & (a.ns - 1);           // flattened k
   const _Float16* xr = a.in_re + fft * a.in_stride + j;
   const _Float16* xi = a.in_im + fft * a.in_stride + j;
   cf v[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) v[i] = cf{static_cast<float>(xr[i * m]), static_cast<float>(xi[i * m])};
-  if (a.ns > 1) {
-    const uint64_t step = k * a.tw_mul;      // < N / R
+  if ((a.ns >> a.inner_shift) > 1 && !a.skip_tw) {
+    const uint64_t step = (k >> a.inner_shift) * a.tw_mul;      // < N / R
 #pragma unroll
     for (int i = 1; i < R; ++i) {
       const uint64_t e = (i * step) & (a.n - 1);

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "k4096.hpp"
+#include "colfft.hpp"
 #include "stockham.hpp"
 
 namespace {
@@ -42,30 +43,31 @@ inline int ilog2(uint64_t x) {
   return l;
 }
 
-enum class Kind { K4096, Stockham };
+enum class PassKind { K4096, Col256, Stockham };
 
 struct Pass {
-  int radix;
-  uint64_t ns;
+  PassKind kind;
+  int radix;          // 4096, 256, or 2/4/8/16
+  uint64_t ns;        // unflattened product of the radices before this pass
+  bool tw_next;       // Col256: apply the next pass's input twiddles to the output
+  bool skip_tw;       // Stockham: input twiddles were applied by the previous pass
+  int next_radix;     // radix of the following pass (Col256 with tw_next)
 };
 
 }  // namespace
 
 struct tfft_plan {
-  uint64_t n = 0, batch = 0;
+  uint64_t n = 0, batch = 0, inner = 1;
   int device = 0;
   uint64_t in_stride = 0, out_stride = 0;
   bool preserve_input = false;
-  Kind kind = Kind::Stockham;
   int num_cus = 0;
   int variant = 0;
-  // K4096
-  void* d_tables = nullptr;
-  // Stockham
   std::vector<Pass> passes;
-  float2* d_tw_lo = nullptr;
+  void* d_tables = nullptr;     // k4096::build_tables blob (K4096 and Col256 passes)
+  float2* d_tw_lo = nullptr;    // w_n tables (Col256 and Stockham passes)
   float2* d_tw_hi = nullptr;
-  // scratch: one [batch][2n] block of halves
+  // scratch: one [batch][2 n inner] block of halves
   mutable std::mutex ws_mutex;
   mutable void* ws = nullptr;
   mutable size_t ws_bytes = 0;
@@ -76,7 +78,7 @@ namespace {
 
 template <int V>
 int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                   hipStream_t s) {
+                   uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
   static std::once_flag once[16];   // per device: opt in to the full 160 KiB of LDS
   hipError_t attr = hipSuccess;
   std::call_once(once[p->device & 15], [&] {
@@ -89,30 +91,80 @@ int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, voi
   const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
   hipLaunchKernelGGL(k4096::fft4096_kernel<V>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
-                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), p->in_stride,
-                     p->out_stride, static_cast<uint32_t>(p->batch),
-                     static_cast<const uint8_t*>(p->d_tables));
-  TFFT_HIP(hipGetLastError());
+                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
   return TFFT_OK;
 }
 
 int launch_k4096(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                 hipStream_t s) {
+                 uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
   // opts.variant: 0 = default (staged, coalesced, non-temporal stores: the fastest measured on MI355X);
   // otherwise a mask of k4096::kPrefetch / kStageOut / kFakeStore / kNonTemporal, with 16 = "none of them".
   const int v = p->variant == 0 ? (k4096::kStageOut | k4096::kNonTemporal) : (p->variant & 15);
+#define TFFT_V(N) case N: return launch_k4096_v<N>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s)
   switch (v) {
-    case 0: return launch_k4096_v<0>(p, in_re, in_im, out_re, out_im, s);
-    case 1: return launch_k4096_v<1>(p, in_re, in_im, out_re, out_im, s);
-    case 2: return launch_k4096_v<2>(p, in_re, in_im, out_re, out_im, s);
-    case 4: return launch_k4096_v<4>(p, in_re, in_im, out_re, out_im, s);
-    case 5: return launch_k4096_v<5>(p, in_re, in_im, out_re, out_im, s);
-    case 8: return launch_k4096_v<8>(p, in_re, in_im, out_re, out_im, s);
-    case 9: return launch_k4096_v<9>(p, in_re, in_im, out_re, out_im, s);
-    case 10: return launch_k4096_v<10>(p, in_re, in_im, out_re, out_im, s);
-    case 13: return launch_k4096_v<13>(p, in_re, in_im, out_re, out_im, s);
+    TFFT_V(0); TFFT_V(1); TFFT_V(2); TFFT_V(4); TFFT_V(5); TFFT_V(8); TFFT_V(9); TFFT_V(10); TFFT_V(13);
     default: return fail(TFFT_ERR_ARG, "unknown kernel variant");
   }
+#undef TFFT_V
+}
+
+struct Planes {
+  _Float16* re;
+  _Float16* im;
+  uint64_t stride;
+};
+
+template <int MODE, bool TW>
+int launch_col_t(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
+  static std::once_flag once[16];
+  hipError_t attr = hipSuccess;
+  std::call_once(once[p->device & 15], [&] {
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_kernel<MODE, TW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kLdsBytes);
+  });
+  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+  const uint32_t blocks_needed = (a.tasks + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock;
+  const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
+  hipLaunchKernelGGL((colfft::colfft256_kernel<MODE, TW>), dim3(grid), dim3(k4096::kThreads), colfft::kLdsBytes, s, a);
+  return TFFT_OK;
+}
+
+int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipStream_t s) {
+  colfft::Args a;
+  a.in_re = reinterpret_cast<const uint16_t*>(src.re);
+  a.in_im = reinterpret_cast<const uint16_t*>(src.im);
+  a.out_re = reinterpret_cast<uint16_t*>(dst.re);
+  a.out_im = reinterpret_cast<uint16_t*>(dst.im);
+  a.in_stride = src.stride;
+  a.out_stride = dst.stride;
+  a.pitch = (p->n / 256) * p->inner;
+  a.ns_f = ps.ns * p->inner;
+  a.ns_f_shift = static_cast<uint32_t>(ilog2(a.ns_f));
+  a.groups = static_cast<uint32_t>(a.pitch / 16);
+  a.tasks = static_cast<uint32_t>(a.groups * p->batch);
+  a.inner_shift = static_cast<uint32_t>(ilog2(p->inner));
+  a.ns = ps.ns;
+  a.tw_lo = p->d_tw_lo;
+  a.tw_hi = p->d_tw_hi;
+  a.tables = static_cast<const uint8_t*>(p->d_tables);
+  a.n_mask = p->n - 1;
+  a.a_shift = 0;
+  a.t_mask = 0;
+  a.n_over_t = 1;
+  if (ps.tw_next) {
+    // next pass: radix R', Ns'' = ns * 256; it wants w_T^(i' k''), T = Ns'' R', on element
+    // o = rest (ns_f 256) + k ns_f + kprev_f:  k'' = k ns + kprev,  i' = o / (n_f / R') = rest >> a_shift
+    const uint64_t t = ps.ns * 256 * static_cast<uint64_t>(ps.next_radix);
+    a.t_mask = t - 1;
+    a.n_over_t = p->n / t;
+    a.a_shift = static_cast<uint32_t>(ilog2(p->n / (static_cast<uint64_t>(ps.next_radix) * ps.ns * 256)));
+  }
+  const bool on_lanes = (a.ns_f == 1);
+  if (on_lanes) return ps.tw_next ? launch_col_t<colfft::kColsOnLanes, true>(p, a, s)
+                                  : launch_col_t<colfft::kColsOnLanes, false>(p, a, s);
+  return ps.tw_next ? launch_col_t<colfft::kColsInRegs, true>(p, a, s)
+                    : launch_col_t<colfft::kColsInRegs, false>(p, a, s);
 }
 
 template <int R>
@@ -122,11 +174,31 @@ void launch_pass(const stockham::PassArgs& a, uint64_t batch, hipStream_t s) {
                      s, a);
 }
 
-struct Planes {
-  _Float16* re;
-  _Float16* im;
-  uint64_t stride;
-};
+void launch_stockham_pass(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipStream_t s) {
+  stockham::PassArgs a;
+  a.in_re = src.re;
+  a.in_im = src.im;
+  a.out_re = dst.re;
+  a.out_im = dst.im;
+  a.in_stride = src.stride;
+  a.out_stride = dst.stride;
+  a.n = p->n;
+  const int R = ps.radix;
+  a.m_f = (p->n / R) * p->inner;
+  a.ns = ps.ns * p->inner;
+  a.inner_shift = static_cast<uint32_t>(ilog2(p->inner));
+  a.skip_tw = ps.skip_tw ? 1u : 0u;
+  a.tw_mul = p->n / (ps.ns * R);
+  a.blocks_per_fft = (a.m_f + stockham::kBlock - 1) / stockham::kBlock;
+  a.tw_lo = p->d_tw_lo;
+  a.tw_hi = p->d_tw_hi;
+  switch (R) {
+    case 2: launch_pass<2>(a, p->batch, s); break;
+    case 4: launch_pass<4>(a, p->batch, s); break;
+    case 8: launch_pass<8>(a, p->batch, s); break;
+    default: launch_pass<16>(a, p->batch, s); break;
+  }
+}
 
 int ensure_workspace(const tfft_plan* p) {
   std::lock_guard<std::mutex> lock(p->ws_mutex);
@@ -141,9 +213,17 @@ int ensure_workspace(const tfft_plan* p) {
   return TFFT_OK;
 }
 
-int launch_stockham(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                    hipStream_t s) {
-  const int np = static_cast<int>(p->passes.size());
+int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                 hipStream_t s) {
+  int np = static_cast<int>(p->passes.size());
+  if ((p->variant >> 8) & 15) np = std::min(np, (p->variant >> 8) & 15);   // debugging aid: run only the first passes
+  if (np == 1 && p->passes[0].kind == PassKind::K4096) {
+    const int rc = launch_k4096(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s);
+    if (rc) return rc;
+    TFFT_HIP(hipGetLastError());
+    return TFFT_OK;
+  }
+  const uint64_t nf = p->n * p->inner;
   Planes IN{const_cast<_Float16*>(static_cast<const _Float16*>(in_re)),
             const_cast<_Float16*>(static_cast<const _Float16*>(in_im)), p->in_stride};
   Planes OUT{static_cast<_Float16*>(out_re), static_cast<_Float16*>(out_im), p->out_stride};
@@ -159,42 +239,27 @@ int launch_stockham(const tfft_plan* p, const void* in_re, const void* in_im, vo
     const int rc = ensure_workspace(p);
     if (rc) return rc;
     _Float16* w = static_cast<_Float16*>(p->ws);
-    SCR = Planes{w, w + p->n, 2 * p->n};
+    SCR = Planes{w, w + nf, 2 * nf};
     if (in_place && odd) {
       // chain IN -> OUT would read and write the same block: start from a copy.
-      if (p->in_stride != 2 * p->n || static_cast<const _Float16*>(in_im) != static_cast<const _Float16*>(in_re) + p->n)
+      if (p->in_stride != 2 * nf || static_cast<const _Float16*>(in_im) != static_cast<const _Float16*>(in_re) + nf)
         return fail(TFFT_ERR_ARG, "in-place execution of this length needs the [RE|IM] block layout (batch stride 2N)");
-      const uint64_t n32 = p->batch * p->n;          // 4 bytes per complex sample
+      const uint64_t n32 = p->batch * nf;          // 4 bytes per complex sample
       hipLaunchKernelGGL(stockham::copy_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>((n32 + 255) / 256, 8192))),
                          dim3(stockham::kBlock), 0, s, static_cast<const uint32_t*>(in_re), static_cast<uint32_t*>(p->ws), n32);
       SRC = SCR;
-      // second scratch is not available: alternate OUT / WS still works because the
-      // first pass reads WS and writes OUT, the next reads OUT and writes WS, ...
     }
   }
   Planes cur = SRC;
   for (int i = 0; i < np; ++i) {
     const bool to_out = ((np - 1 - i) % 2) == 0;
-    Planes dst = to_out ? OUT : SCR;
-    stockham::PassArgs a;
-    a.in_re = cur.re;
-    a.in_im = cur.im;
-    a.out_re = dst.re;
-    a.out_im = dst.im;
-    a.in_stride = cur.stride;
-    a.out_stride = dst.stride;
-    a.n = p->n;
-    a.ns = p->passes[i].ns;
-    const int R = p->passes[i].radix;
-    a.tw_mul = p->n / (a.ns * R);
-    a.blocks_per_fft = (p->n / R + stockham::kBlock - 1) / stockham::kBlock;
-    a.tw_lo = p->d_tw_lo;
-    a.tw_hi = p->d_tw_hi;
-    switch (R) {
-      case 2: launch_pass<2>(a, p->batch, s); break;
-      case 4: launch_pass<4>(a, p->batch, s); break;
-      case 8: launch_pass<8>(a, p->batch, s); break;
-      default: launch_pass<16>(a, p->batch, s); break;
+    const Planes dst = to_out ? OUT : SCR;
+    const Pass& ps = p->passes[i];
+    if (ps.kind == PassKind::Col256) {
+      const int rc = launch_col(p, ps, cur, dst, s);
+      if (rc) return rc;
+    } else {
+      launch_stockham_pass(p, ps, cur, dst, s);
     }
     cur = dst;
   }
@@ -289,10 +354,13 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
   if (!is_pow2(n)) return fail(TFFT_ERR_NOT_POW2, "Error! Input size has to be a power of 2!");
   if (n < 2) return fail(TFFT_ERR_TOO_SMALL, "Error! Input size has to be at least 2");
   if (batch == 0 || batch > 0xffffffffull) return fail(TFFT_ERR_ARG, "batch must be in [1, 2^32)");
-  const uint64_t in_stride = (opts && opts->in_batch_stride) ? opts->in_batch_stride : 2 * n;
-  const uint64_t out_stride = (opts && opts->out_batch_stride) ? opts->out_batch_stride : 2 * n;
-  if (n >= 8 && ((in_stride % 8) || (out_stride % 8))) return fail(TFFT_ERR_ARG, "batch strides must be multiples of 8 halves (16 bytes)");
-  if (in_stride < n || out_stride < n) return fail(TFFT_ERR_ARG, "batch stride smaller than the FFT length");
+  const uint64_t inner = (opts && opts->inner) ? opts->inner : 1;
+  if (!is_pow2(inner) || (inner > 1 && inner < 8)) return fail(TFFT_ERR_ARG, "inner (strided-axis batch) must be 1 or a power of two >= 8");
+  const uint64_t nf = n * inner;
+  const uint64_t in_stride = (opts && opts->in_batch_stride) ? opts->in_batch_stride : 2 * nf;
+  const uint64_t out_stride = (opts && opts->out_batch_stride) ? opts->out_batch_stride : 2 * nf;
+  if (nf >= 8 && ((in_stride % 8) || (out_stride % 8))) return fail(TFFT_ERR_ARG, "batch strides must be multiples of 8 halves (16 bytes)");
+  if (in_stride < nf || out_stride < nf) return fail(TFFT_ERR_ARG, "batch stride smaller than the FFT length");
   int rc = tfft_device_check(device_id);
   if (rc) return rc;
   int prev = 0;
@@ -301,6 +369,7 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
   tfft_plan* p = new tfft_plan;
   p->n = n;
   p->batch = batch;
+  p->inner = inner;
   p->device = device_id;
   p->in_stride = in_stride;
   p->out_stride = out_stride;
@@ -314,26 +383,45 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     (void)hipSetDevice(prev);
     return code;
   };
-  if (n == 4096) {
-    p->kind = Kind::K4096;
+  // ---- pass list. Radix-256 column passes first (they hand the next pass its twiddles), then
+  // radix-16 and one radix-2/4/8 autosort pass. variant bit 32 forces the plain autosort chain.
+  const int lg = ilog2(n);
+  const bool force_stockham = opts && (opts->variant & 32);
+  bool need_tables = false;
+  if (n == 4096 && inner == 1 && !force_stockham) {
+    p->passes.push_back(Pass{PassKind::K4096, 4096, 1, false, false, 0});
+    need_tables = true;
+  } else {
+    int n256 = 0;
+    const bool col_ok = !force_stockham && (inner == 1 ? lg >= 13 : (lg >= 8 && inner >= 16));
+    if (col_ok) n256 = lg / 8;
+    int rem = lg - 8 * n256;
+    std::vector<int> radices(n256, 256);
+    for (; rem >= 4; rem -= 4) radices.push_back(16);
+    if (rem) radices.push_back(1 << rem);
+    uint64_t ns = 1;
+    for (size_t i = 0; i < radices.size(); ++i) {
+      const int R = radices[i];
+      const bool last = (i + 1 == radices.size());
+      if (R == 256) {
+        p->passes.push_back(Pass{PassKind::Col256, 256, ns, !last, false, last ? 0 : radices[i + 1]});
+        need_tables = true;
+      } else {
+        const bool prev_col = i > 0 && radices[i - 1] == 256;
+        p->passes.push_back(Pass{PassKind::Stockham, R, ns, false, prev_col, 0});
+      }
+      ns *= static_cast<uint64_t>(R);
+    }
+  }
+  if (need_tables) {
     std::vector<uint8_t> blob;
     k4096::build_tables(blob);
     e = hipMalloc(&p->d_tables, blob.size());
     if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(tables)"));
     e = hipMemcpy(p->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tables)"));
-  } else {
-    p->kind = Kind::Stockham;
-    const int lg = ilog2(n);
-    uint64_t ns = 1;
-    if (lg % 4) {
-      p->passes.push_back(Pass{1 << (lg % 4), ns});
-      ns <<= (lg % 4);
-    }
-    for (int i = 0; i < lg / 4; ++i) {
-      p->passes.push_back(Pass{16, ns});
-      ns *= 16;
-    }
+  }
+  if (!(p->passes.size() == 1 && p->passes[0].kind == PassKind::K4096)) {
     const uint64_t lo_n = std::min<uint64_t>(n, stockham::kTwLoSize);
     const uint64_t hi_n = n > stockham::kTwLoSize ? n / stockham::kTwLoSize : 0;
     std::vector<float2> lo(lo_n), hi(hi_n);
@@ -355,8 +443,9 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
       e = hipMemcpy(p->d_tw_hi, hi.data(), hi_n * sizeof(float2), hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tw_hi)"));
     }
-    const uint64_t max_blocks = ((n / 2 + stockham::kBlock - 1) / stockham::kBlock) * batch;
+    const uint64_t max_blocks = ((nf / 2 + stockham::kBlock - 1) / stockham::kBlock) * batch;
     if (max_blocks > 0x7fffffffull) return bail(fail(TFFT_ERR_ARG, "batch * N too large for one launch"));
+    if ((nf / 16) * batch > 0xffffffffull) return bail(fail(TFFT_ERR_ARG, "batch * N too large for one launch"));
   }
   (void)hipSetDevice(prev);
   *out = p;
@@ -372,14 +461,14 @@ void tfft_plan_destroy(tfft_plan* p) {
   delete p;
 }
 
-int tfft_plan_num_launches(const tfft_plan* p) {
-  if (!p) return 0;
-  return p->kind == Kind::K4096 ? 1 : static_cast<int>(p->passes.size());
-}
+int tfft_plan_num_launches(const tfft_plan* p) { return p ? static_cast<int>(p->passes.size()) : 0; }
 
 size_t tfft_plan_workspace_bytes(const tfft_plan* p) {
-  if (!p || p->kind == Kind::K4096) return 0;
-  return static_cast<size_t>(p->batch) * p->n * 4;   // [batch][RE n | IM n] halves
+  if (!p || p->passes.size() == 1) {
+    // a single pass needs scratch only when asked to run in place
+    if (!p || p->passes[0].kind == PassKind::K4096) return 0;
+  }
+  return static_cast<size_t>(p->batch) * p->n * p->inner * 4;   // [batch][RE | IM] halves
 }
 
 int tfft_plan_set_workspace(tfft_plan* p, void* device_ptr, size_t bytes) {
@@ -397,33 +486,38 @@ int tfft_exec(const tfft_plan* p, const void* in_re, const void* in_im, void* ou
   g_err.clear();
   if (!p) return fail(TFFT_ERR_ARG, "null plan");
   if (!in_re || !in_im || !out_re || !out_im) return fail(TFFT_ERR_ARG, "null data pointer");
-  const uintptr_t align = (p->n >= 8) ? 15 : (2 * p->n - 1);
+  const uint64_t nf = p->n * p->inner;
+  const uintptr_t align = (nf >= 8) ? 15 : (2 * nf - 1);
   if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im) | reinterpret_cast<uintptr_t>(out_re) |
        reinterpret_cast<uintptr_t>(out_im)) & align)
     return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
   int cur = 0;
   TFFT_HIP(hipGetDevice(&cur));
   if (cur != p->device) return fail(TFFT_ERR_ARG, "plan was created for another device than the current one");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (p->kind == Kind::K4096) return launch_k4096(p, in_re, in_im, out_re, out_im, s);
-  return launch_stockham(p, in_re, in_im, out_re, out_im, s);
+  return launch_chain(p, in_re, in_im, out_re, out_im, static_cast<hipStream_t>(stream));
 }
 
 const char* tfft_plan_kernel_name(const tfft_plan* p) {
   if (!p) return "";
-  return p->kind == Kind::K4096 ? "fft4096_kernel" : "pass_kernel";
+  switch (p->passes[0].kind) {
+    case PassKind::K4096: return "fft4096_kernel";
+    case PassKind::Col256: return "colfft256_kernel";
+    default: return "pass_kernel";
+  }
 }
 
 double tfft_plan_algorithmic_bytes(const tfft_plan* p) {
   if (!p) return 0.0;
-  const double samples = static_cast<double>(p->n) * static_cast<double>(p->batch);
+  const double samples = static_cast<double>(p->n) * static_cast<double>(p->inner) * static_cast<double>(p->batch);
   return 8.0 * samples * tfft_plan_num_launches(p);   // 4 B read + 4 B written per sample per pass
 }
 
 double tfft_plan_mfma_flops(const tfft_plan* p) {
-  if (!p || p->kind != Kind::K4096) return 0.0;
-  // 3 stages x 16 tiles x 2 MFMA(16x16x32) x 16384 flop per 4096 samples = 384 flop/sample
-  return 384.0 * static_cast<double>(p->n) * static_cast<double>(p->batch);
+  if (!p) return 0.0;
+  // one radix-16 MFMA stage = 16 tiles x 2 MFMA(16x16x32) x 16384 flop per 4096 samples = 128 flop/sample
+  double stages = 0;
+  for (const Pass& ps : p->passes) stages += ps.kind == PassKind::K4096 ? 3 : (ps.kind == PassKind::Col256 ? 2 : 0);
+  return 128.0 * stages * static_cast<double>(p->n) * static_cast<double>(p->inner) * static_cast<double>(p->batch);
 }
 
 }  // extern "C"

@@ -234,6 +234,42 @@ def test_generic_lengths(tf, torch, orc, lg):
     assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16))
 
 
+@pytest.mark.parametrize("lg", [13, 16, 17])
+def test_plain_autosort_chain_still_correct(tf, torch, orc, lg):
+    """variant bit 32 forces the radix-2/4/8/16 autosort chain (no radix-256 column kernel)."""
+    n = 1 << lg
+    rng = np.random.default_rng(300 + lg)
+    re = rng.uniform(-1, 1, (3, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (3, n)).astype(np.float16)
+    gr, gi = _run(tf, torch, re, im, variant=32)
+    _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_256)
+
+
+@pytest.mark.parametrize("n,inner", [(256, 16), (256, 64), (4096, 16), (4096, 128), (8192, 32), (1 << 16, 16), (512, 8), (64, 16)])
+def test_transform_along_strided_axis(tf, torch, orc, n, inner):
+    """opts.inner = C: data [batch][n][C], C independent columns innermost (2D column pass, distributed local passes)."""
+    batch = 2
+    rng = np.random.default_rng(n + inner)
+    re = rng.uniform(-1, 1, (batch, n, inner)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n, inner)).astype(np.float16)
+    host = np.stack([re, im], axis=1)                                   # (batch, 2, n, C)
+    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda().reshape(-1)
+    out = torch.full_like(dev, float("nan"))
+    plan = tf.TfftPlan(n, batch, 0, inner=inner)
+    plan.exec(dev, dev[n * inner:], out, out[n * inner:])
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(batch, 2, n, inner)
+    # oracle works on contiguous transforms: move the column axis out
+    cre = np.ascontiguousarray(re.transpose(0, 2, 1)).reshape(-1, n)
+    cim = np.ascontiguousarray(im.transpose(0, 2, 1)).reshape(-1, n)
+    exact = _c(*orc.dft64(cre, cim))
+    got = _c(o[:, 0].transpose(0, 2, 1).reshape(-1, n), o[:, 1].transpose(0, 2, 1).reshape(-1, n))
+    assert np.isfinite(got).all()
+    rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+    assert rel <= REL_L2_TOL, rel
+    assert np.abs(got - exact).max() < 16 * 2.0 ** -11 * np.abs(exact).max()
+
+
 def test_n_2pow20(tf, torch, orc):
     n, batch = 1 << 20, 3
     rng = np.random.default_rng(20)

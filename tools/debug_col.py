@@ -1,0 +1,55 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import __graft_entry__ as g
+g.build()
+import tensor_fft_amd as tf
+def run(n, inner, batch=2, **kw):
+    rng = np.random.default_rng(1)
+    re = rng.uniform(-1, 1, (batch, n, inner)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n, inner)).astype(np.float16)
+    host = np.stack([re, im], axis=1)
+    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda().reshape(-1)
+    out = torch.full_like(dev, float("nan"))
+    plan = tf.TfftPlan(n, batch, 0, inner=inner, **kw)
+    plan.exec(dev, dev[n * inner:], out, out[n * inner:])
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(batch, 2, n, inner).astype(np.float64)
+    x = re.astype(np.float64) + 1j * im.astype(np.float64)
+    ex = np.fft.fft(x, axis=1) / n
+    got = o[:, 0] + 1j * o[:, 1]
+    err = np.abs(got - ex)
+    rel = np.linalg.norm(got - ex) / np.linalg.norm(ex)
+    print(f"n={n} inner={inner} launches={plan.num_launches} rel={rel:.3e} nan={np.isnan(got).sum()}")
+    if rel > 2e-3:
+        bad = np.argwhere(err > 5e-3 * np.abs(ex).max())
+        print("  bad count", len(bad), "first", bad[:8].tolist())
+        ks = np.unique(bad[:, 1]); cs = np.unique(bad[:, 2])
+        print("  bad k (first 40):", ks[:40].tolist(), " n bad k:", len(ks), " bad cols:", cs[:20].tolist())
+for n, inner in [(256, 16), (256, 32), (4096, 16), (65536, 1), (8192, 1)]:
+    run(n, inner)
+print("---- first pass only, N=8192")
+n = 8192; M = n // 256; Rn = 16
+rng = np.random.default_rng(2)
+re = rng.uniform(-1, 1, (1, n)).astype(np.float16); im = rng.uniform(-1, 1, (1, n)).astype(np.float16)
+dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+out = torch.full_like(dev, float("nan"))
+plan = tf.TfftPlan(n, 1, 0, variant=(1 << 8))
+plan.exec(dev, dev[n:], out, out[n:]); torch.cuda.synchronize()
+o = out.cpu().numpy().reshape(2, n).astype(np.float64); got = (o[0] + 1j * o[1]).reshape(M, 256)
+x = (re[0].astype(np.float64) + 1j * im[0].astype(np.float64)).reshape(256, M)      # [i][m]
+Y = np.fft.fft(x, axis=0).T / 256                                                  # [m][k]
+a = np.arange(M)[:, None] // (n // (256 * Rn)); k = np.arange(256)[None, :]
+T = 256 * Rn
+exp = Y * np.exp(-2j * np.pi * (a * k) / T)
+err = np.abs(got - exp)
+print("max err", err.max(), "ref max", np.abs(exp).max())
+bad = np.argwhere(err > 1e-2 * np.abs(exp).max())
+print("bad count", len(bad), bad[:10].tolist())
+if len(bad):
+    print("bad k set:", np.unique(bad[:, 1])[:64].tolist())
+    m, kk = bad[0]
+    print("got", got[m, kk], "exp", exp[m, kk], "untwiddled", Y[m, kk])
+    # is got equal to some other expected element?
+    d = np.abs(exp - got[m, kk]); print("closest expected index", np.unravel_index(d.argmin(), d.shape), d.min())
