@@ -60,6 +60,16 @@ def cpu_baseline(seconds_target=12.0):
     }
 
 
+def shard(rank, world, total):
+    """Contiguous slice [lo, hi) of `total` independent transforms owned by `rank`: the whole multi-GPU story of
+    the batched path (FFTs are independent, no data-path collective). bench.py itself runs weak
+    scaling (every rank a full BASELINE batch); this helper documents and tests the strong-scaling split."""
+    per = total // world
+    extra = total % world
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
 def measured_traffic(kernel_name):
     """HBM bytes per launch from the newest committed PMC summary (tools/summarize_pmc.py; FETCH_SIZE x2 +
     WRITE_SIZE from separate rocprofv3 --pmc passes of this same command), or None."""

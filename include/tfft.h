@@ -124,6 +124,13 @@ int tfft_plan_set_workspace(tfft_plan* plan, void* device_ptr, size_t bytes);
 int tfft_exec(const tfft_plan* plan, const void* in_re, const void* in_im, void* out_re,
               void* out_im, void* stream);
 
+/* out[b][a][c] = in[a][b][c] * w_n_tw^((e0 + b) * (a*C + c)), planar binary16, c contiguous (C % 8 == 0);
+ * n_tw == 0: pure re-ordering. The pack / twiddle / unpack step around the single all-to-all of a transform
+ * distributed over several GPUs; the reference has no counterpart (no multi-device path,
+ * src/base/ComputeFFT.h:295-557 is commented out). Not in place. */
+int tfft_permute_twiddle(const void* in_re, const void* in_im, void* out_re, void* out_im, uint64_t a,
+                         uint64_t b, uint64_t c, uint64_t n_tw, uint64_t e0, void* stream);
+
 /* Name of the dominant kernel of this plan (for profiler summaries) and the
  * algorithmic HBM bytes / MFMA flops of one tfft_exec (SURVEY 8d accounting). */
 const char* tfft_plan_kernel_name(const tfft_plan* plan);

@@ -16,7 +16,7 @@ SYMBOLS = [
     "tfft_ref_create_plan", "tfft_device_check", "tfft_max_no_optin_shared_mem", "tfft_plan_create",
     "tfft_plan_destroy", "tfft_plan_num_launches", "tfft_plan_workspace_bytes", "tfft_plan_set_workspace",
     "tfft_exec", "tfft_plan_kernel_name", "tfft_plan_algorithmic_bytes", "tfft_plan_mfma_flops",
-    "tfft_last_error", "tfft_version",
+    "tfft_last_error", "tfft_version", "tfft_permute_twiddle",
 ]
 
 
@@ -99,6 +99,8 @@ def load_library():
     L.tfft_plan_set_workspace.argtypes = [vp, vp, ctypes.c_size_t]
     L.tfft_exec.restype = ci
     L.tfft_exec.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.tfft_permute_twiddle.restype = ci
+    L.tfft_permute_twiddle.argtypes = [vp, vp, vp, vp, u64, u64, u64, u64, u64, vp]
     L.tfft_plan_kernel_name.restype = ctypes.c_char_p
     L.tfft_plan_kernel_name.argtypes = [vp]
     L.tfft_plan_algorithmic_bytes.restype = ctypes.c_double
@@ -202,3 +204,18 @@ class TfftPlan:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
             self.exec_ptr(in_re.data_ptr(), in_im.data_ptr(), out_re.data_ptr(), out_im.data_ptr(), stream)
+
+
+def permute_twiddle(in_re, in_im, out_re, out_im, a, b, c, n_tw=0, e0=0, stream=None):
+    """out[b][a][c] = in[a][b][c] * w_n_tw^((e0+b)(a*C+c)) on torch CUDA half tensors (tfft_permute_twiddle)."""
+    import torch
+
+    for t in (in_re, in_im, out_re, out_im):
+        if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.numel() >= a * b * c):
+            raise TfftError(5, "planes must be contiguous CUDA float16 tensors of at least A*B*C elements")
+    dev = in_re.device.index
+    if stream is None:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        _check(load_library().tfft_permute_twiddle(in_re.data_ptr(), in_im.data_ptr(), out_re.data_ptr(),
+                                                   out_im.data_ptr(), int(a), int(b), int(c), int(n_tw), int(e0), stream))

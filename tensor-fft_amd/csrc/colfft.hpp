@@ -122,6 +122,26 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
           : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
           : "memory");
     }
+    // (table look-ups issued while the copy is in flight)
+    // ---- twiddle set-up: tw(col, k) = base_r * step^ka with k = ka + 16 kb,
+    //      exponent E = a (kprev + ns k) mod T, a and kprev functions of the column
+    const uint64_t rest = m0 >> a.ns_f_shift;
+    const uint64_t kprev_f0 = m0 - (rest << a.ns_f_shift);
+    cpx base[4], step = {1.f, 0.f};
+    if (TW) {
+      const uint64_t rest_l = (MODE == kColsOnLanes) ? ((m0 + x) >> a.ns_f_shift) : rest;   // this lane's column
+      const uint64_t av = rest_l >> a.a_shift;
+      step = lookup(a, (av * (a.ns & a.t_mask)) & a.t_mask);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t kb = (MODE == kColsOnLanes) ? (4 * g + r) : x;
+        const uint64_t kprev = (MODE == kColsOnLanes)
+                                   ? (((m0 + x) - (rest_l << a.ns_f_shift)) >> a.inner_shift)
+                                   : ((kprev_f0 + 4 * g + r) >> a.inner_shift);
+        base[r] = lookup(a, (av * ((kprev + a.ns * 16 * kb) & a.t_mask)) & a.t_mask);
+      }
+    }
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- stage 1: D1_ilo[ka = 4g + r][column = lane & 15]
@@ -154,25 +174,6 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
         transpose4(pr[0 + pp][r], pr[2 + pp][r], pr[4 + pp][r], pr[6 + pp][r]);
         transpose4(pi[0 + pp][r], pi[2 + pp][r], pi[4 + pp][r], pi[6 + pp][r]);
       }
-
-    // ---- twiddle set-up: tw(col, k) = base_r * step^ka with k = ka + 16 kb,
-    //      exponent E = a (kprev + ns k) mod T, a and kprev functions of the column
-    const uint64_t rest = m0 >> a.ns_f_shift;
-    const uint64_t kprev_f0 = m0 - (rest << a.ns_f_shift);
-    cpx base[4], step = {1.f, 0.f};
-    if (TW) {
-      const uint64_t rest_l = (MODE == kColsOnLanes) ? ((m0 + x) >> a.ns_f_shift) : rest;   // this lane's column
-      const uint64_t av = rest_l >> a.a_shift;
-      step = lookup(a, (av * (a.ns & a.t_mask)) & a.t_mask);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t kb = (MODE == kColsOnLanes) ? (4 * g + r) : x;
-        const uint64_t kprev = (MODE == kColsOnLanes)
-                                   ? (((m0 + x) - (rest_l << a.ns_f_shift)) >> a.inner_shift)
-                                   : ((kprev_f0 + 4 * g + r) >> a.inner_shift);
-        base[r] = lookup(a, (av * ((kprev + a.ns * 16 * kb) & a.t_mask)) & a.t_mask);
-      }
-    }
 
     uint16_t* const o_re = a.out_re + bidx * a.out_stride;
     uint16_t* const o_im = a.out_im + bidx * a.out_stride;

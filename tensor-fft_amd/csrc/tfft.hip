@@ -17,6 +17,7 @@
 
 #include "k4096.hpp"
 #include "colfft.hpp"
+#include "permute.hpp"
 #include "stockham.hpp"
 
 namespace {
@@ -495,6 +496,26 @@ int tfft_exec(const tfft_plan* p, const void* in_re, const void* in_im, void* ou
   TFFT_HIP(hipGetDevice(&cur));
   if (cur != p->device) return fail(TFFT_ERR_ARG, "plan was created for another device than the current one");
   return launch_chain(p, in_re, in_im, out_re, out_im, static_cast<hipStream_t>(stream));
+}
+
+int tfft_permute_twiddle(const void* in_re, const void* in_im, void* out_re, void* out_im, uint64_t a, uint64_t b,
+                         uint64_t c, uint64_t n_tw, uint64_t e0, void* stream) {
+  g_err.clear();
+  if (!in_re || !in_im || !out_re || !out_im) return fail(TFFT_ERR_ARG, "null data pointer");
+  if (a == 0 || b == 0 || c == 0 || (c % 8)) return fail(TFFT_ERR_ARG, "extents must be positive and C a multiple of 8");
+  if (n_tw && !is_pow2(n_tw)) return fail(TFFT_ERR_NOT_POW2, "twiddle modulus has to be a power of 2");
+  if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im) | reinterpret_cast<uintptr_t>(out_re) |
+       reinterpret_cast<uintptr_t>(out_im)) & 15)
+    return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
+  if (in_re == out_re || in_im == out_im) return fail(TFFT_ERR_ARG, "permute cannot run in place");
+  permute::Args pa{static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                   static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), a, b, c / 8, n_tw, e0};
+  const uint64_t total = a * b * (c / 8);
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((total + permute::kBlock - 1) / permute::kBlock, 16384));
+  hipLaunchKernelGGL(permute::permute_twiddle_kernel, dim3(grid), dim3(permute::kBlock), 0,
+                     static_cast<hipStream_t>(stream), pa);
+  TFFT_HIP(hipGetLastError());
+  return TFFT_OK;
 }
 
 const char* tfft_plan_kernel_name(const tfft_plan* p) {

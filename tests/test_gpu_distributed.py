@@ -1,0 +1,71 @@
+"""GPU side of the distributed transform: the fused re-order + twiddle kernel and the driver with the real
+HipEngine at world_size 1 (the multi-rank collectives are covered on CPU over gloo; an 8-GPU run is the
+driver's job). Needs an MI355X: `-m gpu`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tf():
+    import __graft_entry__ as g
+
+    g.build()
+    import tensor_fft_amd as t
+
+    t.device_check(0)
+    return t
+
+
+def _c(re, im):
+    return np.asarray(re, dtype=np.float64) + 1j * np.asarray(im, dtype=np.float64)
+
+
+@pytest.mark.parametrize("a,b,c,n_tw,e0", [(4, 8, 16, 0, 0), (8, 32, 64, 1 << 14, 96), (2, 128, 8, 1 << 11, 0),
+                                            (8, 1024, 1024, 1 << 26, 7 * 1024)])
+def test_permute_twiddle_kernel(tf, a, b, c, n_tw, e0):
+    import torch
+    from tensor_fft_amd import capi
+
+    rng = np.random.default_rng(a * b + c)
+    re = rng.uniform(-1, 1, (a, b, c)).astype(np.float16)
+    im = rng.uniform(-1, 1, (a, b, c)).astype(np.float16)
+    d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
+    o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
+    capi.permute_twiddle(d_re, d_im, o_re, o_im, a, b, c, n_tw, e0)
+    torch.cuda.synchronize()
+    got = _c(o_re.cpu().numpy(), o_im.cpu().numpy()).reshape(b, a, c)
+    want = _c(re, im).transpose(1, 0, 2)
+    if n_tw:
+        row = (e0 + np.arange(b, dtype=np.int64))[:, None, None]
+        col = np.arange(a, dtype=np.int64)[None, :, None] * c + np.arange(c, dtype=np.int64)[None, None, :]
+        want = want * np.exp(-2j * np.pi * ((row * col) % n_tw) / n_tw)
+        assert np.abs(got - want).max() < 2.5e-3          # one fp16 rounding of |x w| <= 1.42
+    else:
+        assert np.array_equal(got, want)
+    with pytest.raises(tf.TfftError):
+        capi.permute_twiddle(d_re, d_im, d_re, d_im, a, b, c)       # in place is refused
+    with pytest.raises(tf.TfftError):
+        capi.load_library()  # keep the import used
+        capi._check(capi.load_library().tfft_permute_twiddle(d_re.data_ptr(), d_im.data_ptr(), o_re.data_ptr(),
+                                                             o_im.data_ptr(), a, b, 12, 0, 0, 0))
+
+
+@pytest.mark.parametrize("lg,out_layout", [(12, "transposed"), (16, "transposed"), (20, "transposed"), (20, "natural"),
+                                           (22, "natural"), (23, "transposed")])
+def test_driver_with_hip_engine_single_rank(tf, orc, lg, out_layout):
+    import torch
+    from tensor_fft_amd.distributed import DistributedFFT1D, HipEngine
+
+    n = 1 << lg
+    rng = np.random.default_rng(lg)
+    xr, xi = rng.uniform(-1, 1, n).astype(np.float16), rng.uniform(-1, 1, n).astype(np.float16)
+    f = DistributedFFT1D(n, engine=HipEngine(0), input_layout="natural", output_layout=out_layout)
+    re, im = f.forward(torch.from_numpy(xr).cuda(), torch.from_numpy(xi).cuda())
+    torch.cuda.synchronize()
+    exact = _c(*orc.dft64(xr, xi))[0]
+    got = _c(re.cpu().numpy(), im.cpu().numpy())
+    want = exact[f.output_indices()]
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel < 1.5e-3, rel
