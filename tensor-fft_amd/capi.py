@@ -219,3 +219,33 @@ def permute_twiddle(in_re, in_im, out_re, out_im, a, b, c, n_tw=0, e0=0, stream=
     with torch.cuda.device(dev):
         _check(load_library().tfft_permute_twiddle(in_re.data_ptr(), in_im.data_ptr(), out_re.data_ptr(),
                                                    out_im.data_ptr(), int(a), int(b), int(c), int(n_tw), int(e0), stream))
+
+
+class TfftPlan2D:
+    """2D transform of `batch` images [rows][cols] (fully planar: all RE images, then all IM images), result
+    DFT2(x) / (rows * cols). Composed of two 1D plans of the C ABI, as BASELINE config 4 describes it: a row
+    pass over contiguous lines (N = cols, batch = batch * rows) and a column pass along the strided axis
+    (N = rows, inner = cols). The reference has no 2D transform; this is its 1D path used twice."""
+
+    def __init__(self, rows, cols, batch=1, device=0):
+        self.rows, self.cols, self.batch, self.device = int(rows), int(cols), int(batch), int(device)
+        self.row_plan = TfftPlan(cols, batch * rows, device, in_batch_stride=cols, out_batch_stride=cols,
+                                 preserve_input=True)
+        self.col_plan = TfftPlan(rows, batch, device, in_batch_stride=rows * cols, out_batch_stride=rows * cols,
+                                 inner=cols)
+        self._tmp = None
+
+    @property
+    def num_launches(self):
+        return self.row_plan.num_launches + self.col_plan.num_launches
+
+    def exec(self, in_re, in_im, out_re, out_im, stream=None):
+        import torch
+
+        n = self.batch * self.rows * self.cols
+        if self._tmp is None or self._tmp[0].numel() < n or self._tmp[0].device != in_re.device:
+            self._tmp = (torch.empty(n, dtype=torch.float16, device=in_re.device),
+                         torch.empty(n, dtype=torch.float16, device=in_re.device))
+        t_re, t_im = self._tmp
+        self.row_plan.exec(in_re, in_im, t_re, t_im, stream)
+        self.col_plan.exec(t_re, t_im, out_re, out_im, stream)

@@ -270,6 +270,50 @@ def test_transform_along_strided_axis(tf, torch, orc, n, inner):
     assert np.abs(got - exact).max() < 16 * 2.0 ** -11 * np.abs(exact).max()
 
 
+@pytest.mark.parametrize("rows,cols,batch", [(256, 512, 3), (4096, 256, 1), (512, 4096, 2)])
+def test_2d_transform(tf, torch, rows, cols, batch):
+    """BASELINE config 4 shape (row FFT, then column FFT along the strided axis), small instances vs numpy fft2."""
+    rng = np.random.default_rng(rows + cols)
+    re = rng.uniform(-1, 1, (batch, rows, cols)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, rows, cols)).astype(np.float16)
+    d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
+    o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
+    plan = tf.TfftPlan2D(rows, cols, batch, 0)
+    plan.exec(d_re, d_im, o_re, o_im)
+    torch.cuda.synchronize()
+    got = _c(o_re.cpu().numpy(), o_im.cpu().numpy()).reshape(batch, rows, cols)
+    exact = np.fft.fft2(_c(re, im), axes=(1, 2)) / (rows * cols)
+    rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+    assert rel <= REL_L2_TOL, rel
+
+
+def test_2d_4096_square_properties(tf, torch):
+    """One 4096 x 4096 image (BASELINE config 4 has 64 of them): impulse -> flat, plane wave -> single bin, Parseval."""
+    n = 4096
+    re = torch.zeros(3, n, n, dtype=torch.float16, device="cuda")
+    im = torch.zeros_like(re)
+    re[0, 3, 5] = 4096.0                   # amplitude 2^12 keeps |X| = 2^-12 clear of fp16 subnormals
+    yy, xx = torch.meshgrid(torch.arange(n, device="cuda"), torch.arange(n, device="cuda"), indexing="ij")
+    ph = 2 * np.pi * ((7 * yy + 11 * xx) % n).double() / n
+    re[1], im[1] = torch.cos(ph).half(), torch.sin(ph).half()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    re[2] = (torch.rand(n, n, device="cuda", generator=gen) * 2 - 1).half()
+    im[2] = (torch.rand(n, n, device="cuda", generator=gen) * 2 - 1).half()
+    o_re, o_im = torch.empty_like(re), torch.empty_like(im)
+    plan = tf.TfftPlan2D(n, n, 3, 0)
+    plan.exec(re.reshape(-1), im.reshape(-1), o_re.reshape(-1), o_im.reshape(-1))
+    torch.cuda.synchronize()
+    mag0 = torch.sqrt(o_re[0].float() ** 2 + o_im[0].float() ** 2)
+    assert float((mag0 * n - 1).abs().max()) < 5e-3              # |X| = 4096 / N^2 everywhere
+    assert abs(float(o_re[1, 7, 11]) - 1.0) < 3e-3
+    m1 = torch.sqrt(o_re[1].float() ** 2 + o_im[1].float() ** 2)
+    m1[7, 11] = 0
+    assert float(m1.max()) < 2e-3
+    e_in = float((re[2].float() ** 2 + im[2].float() ** 2).sum()) / (n * n)
+    e_out = float((o_re[2].float() ** 2 + o_im[2].float() ** 2).sum())
+    assert abs(e_out - e_in) / e_in < 5e-3
+
+
 def test_n_2pow20(tf, torch, orc):
     n, batch = 1 << 20, 3
     rng = np.random.default_rng(20)
