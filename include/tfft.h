@@ -124,6 +124,11 @@ int tfft_plan_set_workspace(tfft_plan* plan, void* device_ptr, size_t bytes);
 int tfft_exec(const tfft_plan* plan, const void* in_re, const void* in_im, void* out_re,
               void* out_im, void* stream);
 
+/* Inverse transform with the same plan: out = (1/N) sum_j x[j] exp(+2 pi i jk/N). The reference has no
+ * inverse; it costs nothing here: forward transform with the RE and IM planes exchanged. */
+int tfft_exec_inverse(const tfft_plan* plan, const void* in_re, const void* in_im, void* out_re,
+                      void* out_im, void* stream);
+
 /* out[b][a][c] = in[a][b][c] * w_n_tw^((e0 + b) * (a*C + c)), planar binary16, c contiguous (C % 8 == 0);
  * n_tw == 0: pure re-ordering. The pack / twiddle / unpack step around the single all-to-all of a transform
  * distributed over several GPUs; the reference has no counterpart (no multi-device path,

@@ -16,7 +16,7 @@ SYMBOLS = [
     "tfft_ref_create_plan", "tfft_device_check", "tfft_max_no_optin_shared_mem", "tfft_plan_create",
     "tfft_plan_destroy", "tfft_plan_num_launches", "tfft_plan_workspace_bytes", "tfft_plan_set_workspace",
     "tfft_exec", "tfft_plan_kernel_name", "tfft_plan_algorithmic_bytes", "tfft_plan_mfma_flops",
-    "tfft_last_error", "tfft_version", "tfft_permute_twiddle",
+    "tfft_last_error", "tfft_version", "tfft_permute_twiddle", "tfft_exec_inverse",
 ]
 
 
@@ -99,6 +99,8 @@ def load_library():
     L.tfft_plan_set_workspace.argtypes = [vp, vp, ctypes.c_size_t]
     L.tfft_exec.restype = ci
     L.tfft_exec.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.tfft_exec_inverse.restype = ci
+    L.tfft_exec_inverse.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tfft_permute_twiddle.restype = ci
     L.tfft_permute_twiddle.argtypes = [vp, vp, vp, vp, u64, u64, u64, u64, u64, vp]
     L.tfft_plan_kernel_name.restype = ctypes.c_char_p
@@ -187,6 +189,10 @@ class TfftPlan:
 
     def exec_ptr(self, in_re, in_im, out_re, out_im, stream=0):
         _check(self._lib.tfft_exec(self._h, in_re, in_im, out_re, out_im, stream))
+
+    def exec_inverse(self, in_re, in_im, out_re, out_im, stream=None):
+        """(1/N) sum x[j] exp(+2 pi i jk/N): the forward transform on exchanged planes (tfft_exec_inverse)."""
+        self.exec(in_im, in_re, out_im, out_re, stream)
 
     def exec(self, in_re, in_im, out_re, out_im, stream=None):
         import torch

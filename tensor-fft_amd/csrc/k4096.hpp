@@ -184,7 +184,8 @@ __device__ __forceinline__ f4 mfma(h8 a, h8 b) {
 //               full 1-KiB rows (mutually exclusive with kPrefetch: same LDS bytes).
 //   kFakeStore  timing experiment only (WRONG output): coalesced stores of the raw registers.
 //   kNonTemporal  nt cache policy on the streamed loads and stores (every byte is touched once).
-enum : int { kPrefetch = 1, kStageOut = 2, kFakeStore = 4, kNonTemporal = 8 };
+//   kNoCompute    timing experiment only (WRONG output): copy the LDS image straight out (data-movement ceiling).
+enum : int { kPrefetch = 1, kStageOut = 2, kFakeStore = 4, kNonTemporal = 8, kNoCompute = 64 };
 
 // LDS-DMA of one transform: 16 x global_load_lds_dwordx4 hidden from the compiler's
 // wait-count bookkeeping (inline asm), so that the only waits are the counted ones below.
@@ -289,6 +290,27 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     first = false;
 
+    if (V & kNoCompute) {
+      uint16_t* const f_re = out_re + static_cast<uint64_t>(b) * out_stride;
+      uint16_t* const f_im = out_im + static_cast<uint64_t>(b) * out_stride;
+      u4 vr[8], vi[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        vr[i] = *reinterpret_cast<const u4*>(wl + 1024 * i + 16 * lane);
+        vi[i] = *reinterpret_cast<const u4*>(wl + 8192 + 1024 * i + 16 * lane);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint32_t nb0 = b + stride_b;
+      if (nb0 < batch)
+        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(nb0) * in_stride),
+               reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(nb0) * in_stride), wl_off, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        st<V>(f_re + 512 * i + 8 * lane, vr[i]);
+        st<V>(f_im + 512 * i + 8 * lane, vi[i]);
+      }
+      continue;
+    }
     // ---- stage 1: D1_n1[k0 = 4g + r][n0 = lane & 15], packed over tile pairs
     uint32_t pr[8][4], pi[8][4];   // [t = n1 >> 1][r]: lo half n1 = 2t, hi half n1 = 2t + 1
 #pragma unroll
@@ -346,9 +368,15 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       const u4 graw = *reinterpret_cast<const u4*>(g_tab + k0 * 1024);
       const f4 e_re = mfma(aop, __builtin_bit_cast(h8, graw));
       const f4 e_im = mfma(aop, im_form(graw));
-      // (e_re + i e_im) * w256^(n0 k1)
-      const f4 t_re = e_re * tw_re - e_im * tw_im;
-      const f4 t_im = e_re * tw_im + e_im * tw_re;
+      // (e_re + i e_im) * w256^(n0 k1). Scalar fp32 on purpose (and the library is built with
+      // -fno-slp-vectorize): packed v_pk_*_f32 sequences next to MFMAs were seen to drop an addend
+      // intermittently on gfx950 (colfft.hpp twiddles), and they buy nothing here.
+      f4 t_re, t_im;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        t_re[r4] = __builtin_fmaf(e_re[r4], tw_re[r4], -(e_im[r4] * tw_im[r4]));
+        t_im[r4] = __builtin_fmaf(e_re[r4], tw_im[r4], e_im[r4] * tw_re[r4]);
+      }
       const u4 braw = {pk(t_re[0], t_re[1]), pk(t_re[2], t_re[3]), pk(t_im[0], t_im[1]),
                        pk(t_im[2], t_im[3])};
       const h8 bop = __builtin_bit_cast(h8, braw);

@@ -101,10 +101,10 @@ int launch_k4096(const tfft_plan* p, const void* in_re, const void* in_im, void*
                  uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
   // opts.variant: 0 = default (staged, coalesced, non-temporal stores: the fastest measured on MI355X);
   // otherwise a mask of k4096::kPrefetch / kStageOut / kFakeStore / kNonTemporal, with 16 = "none of them".
-  const int v = p->variant == 0 ? (k4096::kStageOut | k4096::kNonTemporal) : (p->variant & 15);
+  const int v = p->variant == 0 ? (k4096::kStageOut | k4096::kNonTemporal) : (p->variant & (15 | 64));
 #define TFFT_V(N) case N: return launch_k4096_v<N>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s)
   switch (v) {
-    TFFT_V(0); TFFT_V(1); TFFT_V(2); TFFT_V(4); TFFT_V(5); TFFT_V(8); TFFT_V(9); TFFT_V(10); TFFT_V(13);
+    TFFT_V(0); TFFT_V(1); TFFT_V(2); TFFT_V(4); TFFT_V(5); TFFT_V(8); TFFT_V(9); TFFT_V(10); TFFT_V(13); TFFT_V(64); TFFT_V(72); TFFT_V(73);
     default: return fail(TFFT_ERR_ARG, "unknown kernel variant");
   }
 #undef TFFT_V
@@ -405,7 +405,8 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
       const int R = radices[i];
       const bool last = (i + 1 == radices.size());
       if (R == 256) {
-        p->passes.push_back(Pass{PassKind::Col256, 256, ns, !last, false, last ? 0 : radices[i + 1]});
+        const bool no_tw = opts && (opts->variant & 128);   // debugging aid: WRONG results, timing/determinism only
+        p->passes.push_back(Pass{PassKind::Col256, 256, ns, !last && !no_tw, false, last ? 0 : radices[i + 1]});
         need_tables = true;
       } else {
         const bool prev_col = i > 0 && radices[i - 1] == 256;
@@ -516,6 +517,12 @@ int tfft_permute_twiddle(const void* in_re, const void* in_im, void* out_re, voi
                      static_cast<hipStream_t>(stream), pa);
   TFFT_HIP(hipGetLastError());
   return TFFT_OK;
+}
+
+int tfft_exec_inverse(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im, void* stream) {
+  // (1/N) sum_j x[j] exp(+2 pi i jk/N) = swap(F(swap(x))) with swap(a + ib) = b + ia and F the forward,
+  // 1/N-scaled transform: exchanging the RE and IM planes on both sides is the whole inverse.
+  return tfft_exec(p, in_im, in_re, out_im, out_re, stream);
 }
 
 const char* tfft_plan_kernel_name(const tfft_plan* p) {

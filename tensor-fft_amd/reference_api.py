@@ -29,7 +29,7 @@ class Plan:
         "fft_length_", "amount_of_r16_steps_", "amount_of_r2_steps_", "base_fft_mode_", "results_in_results_",
         "base_fft_warps_per_block_", "base_fft_blocksize_", "base_fft_gridsize_", "base_fft_shared_mem_in_bytes_",
         "r16_warps_per_block_", "r16_blocksize_", "r16_gridsize_", "r16_shared_mem_in_bytes_", "r2_blocksize_",
-        "_exec_plans",
+        "_exec_plans", "_variant",
     )
 
     def __init__(self, s):
@@ -48,6 +48,7 @@ class Plan:
         self.r16_shared_mem_in_bytes_ = s.r16_shared_mem_in_bytes
         self.r2_blocksize_ = s.r2_blocksize
         self._exec_plans = {}
+        self._variant = 0          # MI355X tuner knob (sixth column of a tuner file), 0 = default
 
 
 def CreatePlan(fft_length, mode=Mode_256, base_fft_warps_per_block=8, r16_warps_per_block=8, r2_blocksize=256):
@@ -76,7 +77,10 @@ def _create_plan_from_file(fft_length, tuner_results_file):
                 continue
             if int(float(tok[0])) == fft_length:
                 mode = Mode_256 if int(tok[1]) == 256 else Mode_4096
-                return CreatePlan(fft_length, mode, int(tok[2]), int(tok[3]), int(tok[4]))
+                plan = CreatePlan(fft_length, mode, int(tok[2]), int(tok[3]), int(tok[4]))
+                if plan is not None and len(tok) >= 6:      # tools/tuner.py appends the tuned kernel variant
+                    plan._variant = int(tok[5])
+                return plan
     print("Error! Tuner file didnt contain requested fft length.")
     return None
 
@@ -189,7 +193,7 @@ def _exec_plan(fft_plan, batch, device):
     key = (batch, device)
     p = fft_plan._exec_plans.get(key)
     if p is None:
-        p = capi.TfftPlan(fft_plan.fft_length_, batch, device)
+        p = capi.TfftPlan(fft_plan.fft_length_, batch, device, variant=fft_plan._variant)
         fft_plan._exec_plans[key] = p
     return p
 

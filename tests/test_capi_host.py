@@ -74,9 +74,10 @@ def test_create_plan_rejections(capsys):
 
 def test_create_plan_from_tuner_file(tmp_path, capsys):
     f = tmp_path / "TunerResults.dat"
-    f.write_text("4096 4096 16 4 128\n8192 256 8 16 256\n")
+    f.write_text("4096 4096 16 4 128 10\n8192 256 8 16 256\n")
     p = tf.CreatePlan(4096, str(f))
     assert p.base_fft_mode_ == tf.Mode_4096 and p.r16_warps_per_block_ == 4 and p.r2_blocksize_ == 128
+    assert p._variant == 10                                  # sixth column written by tools/tuner.py
     p = tf.CreatePlan(8192, str(f))
     assert p.base_fft_mode_ == tf.Mode_256 and p.r16_warps_per_block_ == 16
     assert tf.CreatePlan(1 << 20, str(f)) is None

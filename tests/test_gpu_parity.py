@@ -369,6 +369,31 @@ def test_reference_api_batch_handler(tf, torch, orc):
     assert bh.dptr_input_IM_[0].data_ptr() == bh.dptr_input_RE_[0].data_ptr() + 2 * n
 
 
+@pytest.mark.parametrize("n", [4096, 1 << 14])
+def test_inverse_is_forward_on_swapped_planes(tf, torch, n):
+    batch = 4
+    rng = np.random.default_rng(n)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    out = torch.empty_like(dev)
+    plan = tf.TfftPlan(n, batch, 0, preserve_input=True)
+    plan.exec_inverse(dev, dev[n:], out, out[n:])
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(batch, 2, n)
+    want = np.fft.ifft(_c(re, im), axis=1)            # numpy's ifft carries the 1/N
+    got = _c(o[:, 0], o[:, 1])
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= REL_L2_TOL
+    # round trip: inverse(forward(x)) = x / N  (each direction scales by 1/N)
+    mid = torch.empty_like(dev)
+    plan.exec(dev, dev[n:], mid, mid[n:])
+    big = (mid.float() * 64).half()                   # keep the second pass out of the subnormal range
+    plan.exec_inverse(big, big[n:], out, out[n:])
+    torch.cuda.synchronize()
+    back = out.cpu().numpy().reshape(batch, 2, n).astype(np.float64) * n / 64
+    assert np.abs(back[:, 0] - re).max() < 0.05 and np.abs(back[:, 1] - im).max() < 0.05
+
+
 def test_argument_errors(tf, torch):
     n = 4096
     plan = tf.TfftPlan(n, 2, 0)

@@ -1,0 +1,30 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import __graft_entry__ as g
+g.build()
+import tensor_fft_amd as tf
+def check(n, batch, reps=30, **kw):
+    x = ((torch.rand(batch * 2 * n, device="cuda") * 2 - 1)).half()
+    plan = tf.TfftPlan(n, batch, 0, preserve_input=True, **kw)
+    ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+    if plan.workspace_bytes: plan.set_workspace(ws)
+    ref = None; diffs = 0; worst = 0
+    for r in range(reps):
+        y = torch.full_like(x, float("nan"))
+        plan.exec(x, x[n:], y, y[n:]); torch.cuda.synchronize()
+        if ref is None: ref = y.clone()
+        else:
+            d = (y != ref) & ~(torch.isnan(y) & torch.isnan(ref))
+            c = int(d.sum())
+            if c:
+                diffs += 1; worst = max(worst, c)
+                if diffs == 1:
+                    idx = torch.nonzero(d).ravel()[:6].tolist()
+                    print("    first differing flat indices", idx, [(i % (2*n)) for i in idx])
+    print(f"n=2^{int(np.log2(n))} batch={batch} {kw}: runs differing from the first: {diffs}/{reps-1}, worst #elements {worst}")
+check(1 << 20, 16, variant=(1 << 8))
+check(1 << 20, 16, variant=(1 << 8) | 128)
+check(1 << 16, 256, variant=(1 << 8))
+check(1 << 16, 256, variant=(1 << 8) | 128)

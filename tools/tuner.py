@@ -1,0 +1,76 @@
+"""Autotuner: the MI355X counterpart of the reference's TunerSingleFFT.cu / BenchUtil.h grid search
+(src/testing/benchmarks/TunerSingleFFT.cu:10-56, BenchUtil.h:77-150, output FileWriter.h:250-269).
+
+The reference searches (mode, base_fft_warps_per_block, r16_warps_per_block, r2_blocksize) and writes
+`N mode a b c` lines that CreatePlan(N, file) reads back (Plan.h:197-255). On MI355X those launch-geometry
+knobs do not exist; what can be tuned is the kernel variant of the N = 4096 path and, for other lengths,
+the pass decomposition (radix-256 column passes vs the plain radix-16 autosort chain). The file keeps the
+reference's five columns (still valid input for its own parser, which ignores further tokens) and appends
+the tuned `variant` as a sixth column, which this repo's CreatePlan(N, file) honours.
+
+    python tools/tuner.py [--out TunerResults.dat] [--min-log2 8] [--max-log2 24] [--samples 20] [--warmup 5]
+"""
+import argparse
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="TunerResults.dat")
+    ap.add_argument("--min-log2", type=int, default=8)
+    ap.add_argument("--max-log2", type=int, default=24)
+    ap.add_argument("--samples", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--total-log2", type=int, default=26, help="batch = 2^total / N transforms per timing")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+
+    g.build()
+    import tensor_fft_amd as tf
+
+    lines = []
+    for lg in range(args.min_log2, args.max_log2 + 1):
+        n = 1 << lg
+        batch = max(1, (1 << args.total_log2) // n)
+        x = (torch.rand(batch * 2 * n, device="cuda") * 2 - 1).half()
+        y = torch.empty_like(x)
+        cands = [16, 2, 10, 8, 1] if n == 4096 else [0, 32]          # 0 is the same as 10 at N = 4096
+        best = None
+        for v in cands:
+            try:
+                plan = tf.TfftPlan(n, batch, 0, variant=v, preserve_input=True)
+            except tf.TfftError:
+                continue
+            ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+            if plan.workspace_bytes:
+                plan.set_workspace(ws)
+            ts = []
+            for k in range(args.warmup + args.samples):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                plan.exec(x, x[n:], y, y[n:])
+                e1.record()
+                torch.cuda.synchronize()
+                if k >= args.warmup:
+                    ts.append(e0.elapsed_time(e1) * 1e6)           # ns, like the reference's timer
+            avg, sig = statistics.mean(ts), (statistics.stdev(ts) if len(ts) > 1 else 0.0)
+            print(f"N=2^{lg} batch={batch} variant={v:2d} launches={plan.num_launches} avg {avg/1e3:9.1f} us sigma {sig/1e3:7.1f} us "
+                  f"{n * batch / avg:7.2f} Gsamples/s")
+            if best is None or avg < best[0]:
+                best = (avg, v)
+        mode = 4096 if n >= 4096 else 256
+        lines.append(f"{n} {mode} {16 if mode == 4096 else 1} 1 256 {best[1]}")
+    with open(args.out, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print(f"wrote {args.out}")
+
+
+if __name__ == "__main__":
+    main()
