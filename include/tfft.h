@@ -136,6 +136,12 @@ int tfft_exec_inverse(const tfft_plan* plan, const void* in_re, const void* in_i
 int tfft_permute_twiddle(const void* in_re, const void* in_im, void* out_re, void* out_im, uint64_t a,
                          uint64_t b, uint64_t c, uint64_t n_tw, uint64_t e0, void* stream);
 
+/* Layout adapters either side of the path: interleaved (re, im) half2 samples, as cuFFT / hipFFT callers and the
+ * reference's comparison code hold them (src/testing/AccuracyCalculator.h:35-48, TestingDataCreation.h half2
+ * generators) <-> the planar layout of this library. count = complex samples, a multiple of 8. */
+int tfft_deinterleave(const void* in_half2, void* out_re, void* out_im, uint64_t count, void* stream);
+int tfft_interleave(const void* in_re, const void* in_im, void* out_half2, uint64_t count, void* stream);
+
 /* Name of the dominant kernel of this plan (for profiler summaries) and the
  * algorithmic HBM bytes / MFMA flops of one tfft_exec (SURVEY 8d accounting). */
 const char* tfft_plan_kernel_name(const tfft_plan* plan);

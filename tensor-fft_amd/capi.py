@@ -16,7 +16,7 @@ SYMBOLS = [
     "tfft_ref_create_plan", "tfft_device_check", "tfft_max_no_optin_shared_mem", "tfft_plan_create",
     "tfft_plan_destroy", "tfft_plan_num_launches", "tfft_plan_workspace_bytes", "tfft_plan_set_workspace",
     "tfft_exec", "tfft_plan_kernel_name", "tfft_plan_algorithmic_bytes", "tfft_plan_mfma_flops",
-    "tfft_last_error", "tfft_version", "tfft_permute_twiddle", "tfft_exec_inverse",
+    "tfft_last_error", "tfft_version", "tfft_permute_twiddle", "tfft_exec_inverse", "tfft_deinterleave", "tfft_interleave",
 ]
 
 
@@ -99,6 +99,10 @@ def load_library():
     L.tfft_plan_set_workspace.argtypes = [vp, vp, ctypes.c_size_t]
     L.tfft_exec.restype = ci
     L.tfft_exec.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.tfft_deinterleave.restype = ci
+    L.tfft_deinterleave.argtypes = [vp, vp, vp, u64, vp]
+    L.tfft_interleave.restype = ci
+    L.tfft_interleave.argtypes = [vp, vp, vp, u64, vp]
     L.tfft_exec_inverse.restype = ci
     L.tfft_exec_inverse.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tfft_permute_twiddle.restype = ci
@@ -255,3 +259,25 @@ class TfftPlan2D:
         t_re, t_im = self._tmp
         self.row_plan.exec(in_re, in_im, t_re, t_im, stream)
         self.col_plan.exec(t_re, t_im, out_re, out_im, stream)
+
+
+def deinterleave(x_half2, out_re, out_im, stream=None):
+    """(count, 2) interleaved half tensor -> planar re, im (tfft_deinterleave)."""
+    import torch
+
+    count = out_re.numel()
+    if stream is None:
+        stream = torch.cuda.current_stream(x_half2.device.index).cuda_stream
+    with torch.cuda.device(x_half2.device.index):
+        _check(load_library().tfft_deinterleave(x_half2.data_ptr(), out_re.data_ptr(), out_im.data_ptr(), count, stream))
+
+
+def interleave(in_re, in_im, out_half2, stream=None):
+    """planar re, im -> (count, 2) interleaved half tensor (tfft_interleave)."""
+    import torch
+
+    count = in_re.numel()
+    if stream is None:
+        stream = torch.cuda.current_stream(in_re.device.index).cuda_stream
+    with torch.cuda.device(in_re.device.index):
+        _check(load_library().tfft_interleave(in_re.data_ptr(), in_im.data_ptr(), out_half2.data_ptr(), count, stream))

@@ -31,7 +31,10 @@ namespace colfft {
 using namespace k4096;
 
 constexpr int kLdsTable = 16384;                                   // G only
-constexpr int kLdsBytes = kLdsTable + kWavesPerBlock * kLdsWaveBytes;   // 144 KiB
+constexpr int kWaveRegion = 18432;                                 // 16 KiB copy-in image, reused (padded) for the output
+constexpr int kStagePitch = 528;                                   // 512 + 16: conflict-free / 2-way staging writes
+constexpr int kStagePlane = 16 * kStagePitch;                      // 8448 B per plane
+constexpr int kLdsBytes = kLdsTable + kWavesPerBlock * kWaveRegion;     // 160 KiB
 
 enum : int { kColsOnLanes = 0, kColsInRegs = 1 };
 
@@ -51,7 +54,8 @@ struct Args {
   uint32_t a_shift;                 // a = rest >> a_shift        (rest = m >> ns_f_shift)
   uint64_t ns;                      // unflattened Ns of THIS pass = ns_f / C
   uint64_t t_mask;                  // T - 1
-  uint64_t n_over_t;                // N / T : exponent scale into the w_N tables
+  uint64_t n_over_t;                // N / T
+  double inv_t;                     // 1 / T
   uint64_t n_mask;                  // N - 1
   const float2* tw_lo;
   const float2* tw_hi;
@@ -63,18 +67,27 @@ struct cpx {
 };
 __device__ __forceinline__ cpx cmul(cpx a, cpx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 
-__device__ __forceinline__ cpx lookup(const Args& a, uint64_t e_t) {   // w_T^(e_t), e_t already reduced mod T
-  const uint64_t e = (e_t * a.n_over_t) & a.n_mask;
-  const float2 lo = a.tw_lo[e & 8191];
-  cpx w = {lo.x, lo.y};
-  if (a.n_mask >= 8192) {
-    const float2 hi = a.tw_hi[e >> 13];
-    w = cmul(w, cpx{hi.x, hi.y});
+// w_T^(e_t) = exp(-2 pi i e_t / T), e_t already reduced mod T.
+// LUT: two-level fp32 tables of w_N (exact to fp32 rounding, but five dependent L2 round trips per task);
+// otherwise v_cos_f32 / v_sin_f32, which take their argument in revolutions (absolute error ~1e-6, far below
+// the fp16 resolution of the data they multiply; no memory access).
+template <bool LUT>
+__device__ __forceinline__ cpx lookup(const Args& a, uint64_t e_t) {
+  if (LUT) {
+    const uint64_t e = (e_t * a.n_over_t) & a.n_mask;
+    const float2 lo = a.tw_lo[e & 8191];
+    cpx w = {lo.x, lo.y};
+    if (a.n_mask >= 8192) {
+      const float2 hi = a.tw_hi[e >> 13];
+      w = cmul(w, cpx{hi.x, hi.y});
+    }
+    return w;
   }
-  return w;
+  const float frac = static_cast<float>(static_cast<double>(e_t) * a.inv_t);
+  return cpx{__builtin_amdgcn_cosf(frac), -__builtin_amdgcn_sinf(frac)};
 }
 
-template <int MODE, bool TW>
+template <int MODE, bool TW, bool STAGE, bool LUT>
 __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -87,7 +100,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  uint8_t* const wl = lds + kLdsTable + wave * kLdsWaveBytes;
+  uint8_t* const wl = lds + kLdsTable + wave * kWaveRegion;
   const uint32_t wl_off = __builtin_amdgcn_readfirstlane(
       static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)wl)));
   const uint8_t* const g_tab = lds + lane * 16;
@@ -131,14 +144,14 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
     if (TW) {
       const uint64_t rest_l = (MODE == kColsOnLanes) ? ((m0 + x) >> a.ns_f_shift) : rest;   // this lane's column
       const uint64_t av = rest_l >> a.a_shift;
-      step = lookup(a, (av * (a.ns & a.t_mask)) & a.t_mask);
+      step = lookup<LUT>(a, (av * (a.ns & a.t_mask)) & a.t_mask);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const uint32_t kb = (MODE == kColsOnLanes) ? (4 * g + r) : x;
         const uint64_t kprev = (MODE == kColsOnLanes)
                                    ? (((m0 + x) - (rest_l << a.ns_f_shift)) >> a.inner_shift)
                                    : ((kprev_f0 + 4 * g + r) >> a.inner_shift);
-        base[r] = lookup(a, (av * ((kprev + a.ns * 16 * kb) & a.t_mask)) & a.t_mask);
+        base[r] = lookup<LUT>(a, (av * ((kprev + a.ns * 16 * kb) & a.t_mask)) & a.t_mask);
       }
     }
 
@@ -206,12 +219,17 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
         pw = cmul(pw, step);
       }
       if (MODE == kColsInRegs) {
-        // 4 adjacent columns 4g..4g+3 of row k = ka + 16 kb: one 8-byte store per plane
-        const uint64_t o = ((rest << 8) << a.ns_f_shift) + (static_cast<uint64_t>(ka + 16 * x) << a.ns_f_shift) + kprev_f0 + 4 * g;
+        // 4 adjacent columns 4g..4g+3 of row k = ka + 16 kb (kb = lane & 15): one 8-byte piece per plane
         const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
         const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
-        *reinterpret_cast<u2*>(o_re + o) = vr;
-        *reinterpret_cast<u2*>(o_im + o) = vi;
+        if (STAGE) {   // staged at 528 kb + 32 ka + 8 g (the 16-byte pad per kb block spreads the lanes over the banks)
+          *reinterpret_cast<u2*>(wl + kStagePitch * x + 32 * ka + 8 * g) = vr;
+          *reinterpret_cast<u2*>(wl + kStagePlane + kStagePitch * x + 32 * ka + 8 * g) = vi;
+        } else {
+          const uint64_t o = ((rest << 8) << a.ns_f_shift) + (static_cast<uint64_t>(ka + 16 * x) << a.ns_f_shift) + kprev_f0 + 4 * g;
+          *reinterpret_cast<u2*>(o_re + o) = vr;
+          *reinterpret_cast<u2*>(o_im + o) = vi;
+        }
       } else {
         if ((ka & 1) == 0) {
 #pragma unroll
@@ -226,20 +244,44 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
             acc_im[r][(ka >> 1) & 3] = pk(hold_im[r], e_im[r]);
           }
           if ((ka & 7) == 7) {
-            // k = 16 (4g + r) + 8 half .. + 7 of column m0 + x: 16 bytes per plane
+            // k = 16 (4g + r) + 8 half .. + 7 of column x: 16 bytes per plane
             const int half = ka >> 3;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const uint64_t o = (m0 + x) * 256 + 16 * (4 * g + r) + 8 * half;
               const u4 vr = {acc_re[r][0], acc_re[r][1], acc_re[r][2], acc_re[r][3]};
               const u4 vi = {acc_im[r][0], acc_im[r][1], acc_im[r][2], acc_im[r][3]};
-              *reinterpret_cast<u4*>(o_re + o) = vr;
-              *reinterpret_cast<u4*>(o_im + o) = vi;
+              if (STAGE) {   // row x of a [column][k] image with 528-byte rows
+                *reinterpret_cast<u4*>(wl + kStagePitch * x + 32 * (4 * g + r) + 16 * half) = vr;
+                *reinterpret_cast<u4*>(wl + kStagePlane + kStagePitch * x + 32 * (4 * g + r) + 16 * half) = vi;
+              } else {
+                const uint64_t o = (m0 + x) * 256 + 16 * (4 * g + r) + 8 * half;
+                *reinterpret_cast<u4*>(o_re + o) = vr;
+                *reinterpret_cast<u4*>(o_im + o) = vi;
+              }
             }
           }
         }
       }
     }
+    // ---- (STAGE) staged image -> HBM, 16 bytes per lane
+#pragma unroll
+    for (int j = 0; STAGE && j < 8; ++j) {
+      const uint32_t off = kStagePitch * (2 * j + (lane >> 5)) + 16 * (lane & 31);
+      const u4 vr = *reinterpret_cast<const u4*>(wl + off);
+      const u4 vi = *reinterpret_cast<const u4*>(wl + kStagePlane + off);
+      uint64_t o;
+      if (MODE == kColsInRegs) {
+        // image row = output row k = 32 j + (lane >> 1), columns 8 (lane & 1) .. + 7: a 32-byte run per row
+        const uint64_t k = 32 * j + (lane >> 1);
+        o = ((rest << 8) << a.ns_f_shift) + (k << a.ns_f_shift) + kprev_f0 + 8 * (lane & 1);
+      } else {
+        // image row = column f = 2 j + (lane >> 5): its 256 outputs are 512 contiguous bytes
+        o = (m0 + 2 * j + (lane >> 5)) * 256 + 8 * (lane & 31);
+      }
+      *reinterpret_cast<u4*>(o_re + o) = vr;
+      *reinterpret_cast<u4*>(o_im + o) = vi;
+    }
+    if (STAGE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image read out before the next copy-in lands on it
   }
 }
 

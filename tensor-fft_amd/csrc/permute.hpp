@@ -62,4 +62,38 @@ __global__ __launch_bounds__(kBlock) void permute_twiddle_kernel(Args p) {
   }
 }
 
+// interleaved half2 [n] (re, im pairs: the layout cuFFT / hipFFT use, reference AccuracyCalculator.h:35-48,
+// TestingDataCreation.h half2 generators) <-> planar re[n], im[n]. 8 complex samples per thread.
+typedef uint32_t uv4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kBlock) void deinterleave_kernel(const uv4* __restrict__ in, uv4* __restrict__ re,
+                                                               uv4* __restrict__ im, uint64_t n8) {
+  for (uint64_t t = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; t < n8;
+       t += static_cast<uint64_t>(gridDim.x) * kBlock) {
+    const uv4 a = in[2 * t], b = in[2 * t + 1];       // 8 (re, im) pairs
+    uv4 r, i;
+    r.x = (a.x & 0xffffu) | (a.y << 16);  i.x = (a.x >> 16) | (a.y & 0xffff0000u);
+    r.y = (a.z & 0xffffu) | (a.w << 16);  i.y = (a.z >> 16) | (a.w & 0xffff0000u);
+    r.z = (b.x & 0xffffu) | (b.y << 16);  i.z = (b.x >> 16) | (b.y & 0xffff0000u);
+    r.w = (b.z & 0xffffu) | (b.w << 16);  i.w = (b.z >> 16) | (b.w & 0xffff0000u);
+    re[t] = r;
+    im[t] = i;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void interleave_kernel(const uv4* __restrict__ re, const uv4* __restrict__ im,
+                                                             uv4* __restrict__ out, uint64_t n8) {
+  for (uint64_t t = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; t < n8;
+       t += static_cast<uint64_t>(gridDim.x) * kBlock) {
+    const uv4 r = re[t], i = im[t];
+    uv4 a, b;
+    a.x = (r.x & 0xffffu) | (i.x << 16);  a.y = (r.x >> 16) | (i.x & 0xffff0000u);
+    a.z = (r.y & 0xffffu) | (i.y << 16);  a.w = (r.y >> 16) | (i.y & 0xffff0000u);
+    b.x = (r.z & 0xffffu) | (i.z << 16);  b.y = (r.z >> 16) | (i.z & 0xffff0000u);
+    b.z = (r.w & 0xffffu) | (i.w << 16);  b.w = (r.w >> 16) | (i.w & 0xffff0000u);
+    out[2 * t] = a;
+    out[2 * t + 1] = b;
+  }
+}
+
 }  // namespace permute

@@ -116,19 +116,28 @@ struct Planes {
   uint64_t stride;
 };
 
-template <int MODE, bool TW>
+template <int MODE, bool TW, bool STAGE, bool LUT>
 int launch_col_t(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   static std::once_flag once[16];
   hipError_t attr = hipSuccess;
   std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_kernel<MODE, TW>),
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_kernel<MODE, TW, STAGE, LUT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kLdsBytes);
   });
   if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint32_t blocks_needed = (a.tasks + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock;
   const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
-  hipLaunchKernelGGL((colfft::colfft256_kernel<MODE, TW>), dim3(grid), dim3(k4096::kThreads), colfft::kLdsBytes, s, a);
+  hipLaunchKernelGGL((colfft::colfft256_kernel<MODE, TW, STAGE, LUT>), dim3(grid), dim3(k4096::kThreads), colfft::kLdsBytes, s, a);
   return TFFT_OK;
+}
+
+template <bool STAGE, bool LUT>
+int launch_col_s(const tfft_plan* p, const Pass& ps, const colfft::Args& a, hipStream_t s) {
+  const bool on_lanes = (a.ns_f == 1);
+  if (on_lanes) return ps.tw_next ? launch_col_t<colfft::kColsOnLanes, true, STAGE, LUT>(p, a, s)
+                                  : launch_col_t<colfft::kColsOnLanes, false, STAGE, false>(p, a, s);
+  return ps.tw_next ? launch_col_t<colfft::kColsInRegs, true, STAGE, LUT>(p, a, s)
+                    : launch_col_t<colfft::kColsInRegs, false, STAGE, false>(p, a, s);
 }
 
 int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipStream_t s) {
@@ -153,19 +162,22 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   a.a_shift = 0;
   a.t_mask = 0;
   a.n_over_t = 1;
+  a.inv_t = 1.0;
   if (ps.tw_next) {
     // next pass: radix R', Ns'' = ns * 256; it wants w_T^(i' k''), T = Ns'' R', on element
     // o = rest (ns_f 256) + k ns_f + kprev_f:  k'' = k ns + kprev,  i' = o / (n_f / R') = rest >> a_shift
     const uint64_t t = ps.ns * 256 * static_cast<uint64_t>(ps.next_radix);
     a.t_mask = t - 1;
     a.n_over_t = p->n / t;
+    a.inv_t = 1.0 / static_cast<double>(t);
     a.a_shift = static_cast<uint32_t>(ilog2(p->n / (static_cast<uint64_t>(ps.next_radix) * ps.ns * 256)));
   }
-  const bool on_lanes = (a.ns_f == 1);
-  if (on_lanes) return ps.tw_next ? launch_col_t<colfft::kColsOnLanes, true>(p, a, s)
-                                  : launch_col_t<colfft::kColsOnLanes, false>(p, a, s);
-  return ps.tw_next ? launch_col_t<colfft::kColsInRegs, true>(p, a, s)
-                    : launch_col_t<colfft::kColsInRegs, false>(p, a, s);
+  // default: stores straight from registers (8- / 16-byte pieces); variant bit 4096: stage the output through
+  // LDS (16-byte coalesced stores). Measured in one process on MI355X: direct wins at 2^16 and 2^20, staging at 2^13.
+  // variant bit 8192: twiddles from v_sin/v_cos instead of the two-level tables
+  const bool stage = p->variant & 4096, hw = p->variant & 8192;
+  if (stage) return hw ? launch_col_s<true, false>(p, ps, a, s) : launch_col_s<true, true>(p, ps, a, s);
+  return hw ? launch_col_s<false, false>(p, ps, a, s) : launch_col_s<false, true>(p, ps, a, s);
 }
 
 template <int R>
@@ -394,7 +406,10 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     need_tables = true;
   } else {
     int n256 = 0;
-    const bool col_ok = !force_stockham && (inner == 1 ? lg >= 13 : (lg >= 8 && inner >= 16));
+    // with >= 256 columns innermost every autosort pass already moves long contiguous runs (measured ~6 TB/s
+    // per radix-16 pass), which beats the column kernel's 32-byte pieces; variant bit 16384 forces the column kernel
+    const bool force_col = opts && (opts->variant & 16384);
+    const bool col_ok = !force_stockham && (inner == 1 ? lg >= 13 : (lg >= 8 && inner >= 16 && (inner < 256 || force_col)));
     if (col_ok) n256 = lg / 8;
     int rem = lg - 8 * n256;
     std::vector<int> radices(n256, 256);
@@ -523,6 +538,36 @@ int tfft_exec_inverse(const tfft_plan* p, const void* in_re, const void* in_im, 
   // (1/N) sum_j x[j] exp(+2 pi i jk/N) = swap(F(swap(x))) with swap(a + ib) = b + ia and F the forward,
   // 1/N-scaled transform: exchanging the RE and IM planes on both sides is the whole inverse.
   return tfft_exec(p, in_im, in_re, out_im, out_re, stream);
+}
+
+int tfft_deinterleave(const void* in_half2, void* out_re, void* out_im, uint64_t count, void* stream) {
+  g_err.clear();
+  if (!in_half2 || !out_re || !out_im) return fail(TFFT_ERR_ARG, "null data pointer");
+  if (count == 0 || (count % 8)) return fail(TFFT_ERR_ARG, "count must be a positive multiple of 8 complex samples");
+  if ((reinterpret_cast<uintptr_t>(in_half2) | reinterpret_cast<uintptr_t>(out_re) | reinterpret_cast<uintptr_t>(out_im)) & 15)
+    return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
+  const uint64_t n8 = count / 8;
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n8 + permute::kBlock - 1) / permute::kBlock, 16384));
+  hipLaunchKernelGGL(permute::deinterleave_kernel, dim3(grid), dim3(permute::kBlock), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const permute::uv4*>(in_half2), static_cast<permute::uv4*>(out_re),
+                     static_cast<permute::uv4*>(out_im), n8);
+  TFFT_HIP(hipGetLastError());
+  return TFFT_OK;
+}
+
+int tfft_interleave(const void* in_re, const void* in_im, void* out_half2, uint64_t count, void* stream) {
+  g_err.clear();
+  if (!in_re || !in_im || !out_half2) return fail(TFFT_ERR_ARG, "null data pointer");
+  if (count == 0 || (count % 8)) return fail(TFFT_ERR_ARG, "count must be a positive multiple of 8 complex samples");
+  if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im) | reinterpret_cast<uintptr_t>(out_half2)) & 15)
+    return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
+  const uint64_t n8 = count / 8;
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n8 + permute::kBlock - 1) / permute::kBlock, 16384));
+  hipLaunchKernelGGL(permute::interleave_kernel, dim3(grid), dim3(permute::kBlock), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const permute::uv4*>(in_re), static_cast<const permute::uv4*>(in_im),
+                     static_cast<permute::uv4*>(out_half2), n8);
+  TFFT_HIP(hipGetLastError());
+  return TFFT_OK;
 }
 
 const char* tfft_plan_kernel_name(const tfft_plan* p) {
