@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "k4096.hpp"
+#include "k256.hpp"
 #include "colfft.hpp"
 #include "permute.hpp"
 #include "stockham.hpp"
@@ -44,7 +45,7 @@ inline int ilog2(uint64_t x) {
   return l;
 }
 
-enum class PassKind { K4096, Col256, Stockham };
+enum class PassKind { K4096, K256, Col256, Stockham };
 
 struct Pass {
   PassKind kind;
@@ -91,6 +92,25 @@ int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, voi
       static_cast<uint32_t>((p->batch + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
   const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
   hipLaunchKernelGGL(k4096::fft4096_kernel<V>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+                     static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
+  return TFFT_OK;
+}
+
+int launch_k256(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
+  static std::once_flag once[16];
+  hipError_t attr = hipSuccess;
+  std::call_once(once[p->device & 15], [&] {
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k256::fft256_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, k256::kLdsBytes);
+  });
+  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+  const uint64_t groups = (p->batch + k256::kFftsPerWave - 1) / k256::kFftsPerWave;
+  const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
+  const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
+  hipLaunchKernelGGL(k256::fft256_kernel, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
                      static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
@@ -230,8 +250,10 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
                  hipStream_t s) {
   int np = static_cast<int>(p->passes.size());
   if ((p->variant >> 8) & 15) np = std::min(np, (p->variant >> 8) & 15);   // debugging aid: run only the first passes
-  if (np == 1 && p->passes[0].kind == PassKind::K4096) {
-    const int rc = launch_k4096(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s);
+  if (np == 1 && (p->passes[0].kind == PassKind::K4096 || p->passes[0].kind == PassKind::K256)) {
+    const int rc = p->passes[0].kind == PassKind::K4096
+                       ? launch_k4096(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s)
+                       : launch_k256(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s);
     if (rc) return rc;
     TFFT_HIP(hipGetLastError());
     return TFFT_OK;
@@ -404,6 +426,9 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
   if (n == 4096 && inner == 1 && !force_stockham) {
     p->passes.push_back(Pass{PassKind::K4096, 4096, 1, false, false, 0});
     need_tables = true;
+  } else if (n == 256 && inner == 1 && !force_stockham) {
+    p->passes.push_back(Pass{PassKind::K256, 256, 1, false, false, 0});
+    need_tables = true;
   } else {
     int n256 = 0;
     // with >= 256 columns innermost every autosort pass already moves long contiguous runs (measured ~6 TB/s
@@ -438,7 +463,7 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     e = hipMemcpy(p->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tables)"));
   }
-  if (!(p->passes.size() == 1 && p->passes[0].kind == PassKind::K4096)) {
+  if (!(p->passes.size() == 1 && (p->passes[0].kind == PassKind::K4096 || p->passes[0].kind == PassKind::K256))) {
     const uint64_t lo_n = std::min<uint64_t>(n, stockham::kTwLoSize);
     const uint64_t hi_n = n > stockham::kTwLoSize ? n / stockham::kTwLoSize : 0;
     std::vector<float2> lo(lo_n), hi(hi_n);
@@ -483,7 +508,7 @@ int tfft_plan_num_launches(const tfft_plan* p) { return p ? static_cast<int>(p->
 size_t tfft_plan_workspace_bytes(const tfft_plan* p) {
   if (!p || p->passes.size() == 1) {
     // a single pass needs scratch only when asked to run in place
-    if (!p || p->passes[0].kind == PassKind::K4096) return 0;
+    if (!p || p->passes[0].kind == PassKind::K4096 || p->passes[0].kind == PassKind::K256) return 0;
   }
   return static_cast<size_t>(p->batch) * p->n * p->inner * 4;   // [batch][RE | IM] halves
 }
@@ -574,6 +599,7 @@ const char* tfft_plan_kernel_name(const tfft_plan* p) {
   if (!p) return "";
   switch (p->passes[0].kind) {
     case PassKind::K4096: return "fft4096_kernel";
+    case PassKind::K256: return "fft256_kernel";
     case PassKind::Col256: return "colfft256_kernel";
     default: return "pass_kernel";
   }
@@ -589,7 +615,8 @@ double tfft_plan_mfma_flops(const tfft_plan* p) {
   if (!p) return 0.0;
   // one radix-16 MFMA stage = 16 tiles x 2 MFMA(16x16x32) x 16384 flop per 4096 samples = 128 flop/sample
   double stages = 0;
-  for (const Pass& ps : p->passes) stages += ps.kind == PassKind::K4096 ? 3 : (ps.kind == PassKind::Col256 ? 2 : 0);
+  for (const Pass& ps : p->passes)
+    stages += ps.kind == PassKind::K4096 ? 3 : ((ps.kind == PassKind::Col256 || ps.kind == PassKind::K256) ? 2 : 0);
   return 128.0 * stages * static_cast<double>(p->n) * static_cast<double>(p->inner) * static_cast<double>(p->batch);
 }
 

@@ -90,6 +90,29 @@ def test_n4096_random_uniform(tf, torch, orc, batch):
     _check_against_oracle(orc, re, im, *g, mode=orc.MODE_4096)
 
 
+@pytest.mark.parametrize("batch", [1, 16, 37, 1000])
+def test_n256_dedicated_kernel(tf, torch, orc, batch):
+    """N = 256 (the reference's TensorFFT256 base case): 16 transforms per wave, ragged last group."""
+    rng = np.random.default_rng(256 + batch)
+    re = rng.uniform(-1, 1, (batch, 256)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, 256)).astype(np.float16)
+    plan = tf.TfftPlan(256, batch, 0)
+    assert plan.kernel_name == "fft256_kernel" and plan.num_launches == 1
+    gr, gi = _run(tf, torch, re, im)
+    _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_256)
+    # in place and fully planar strides give the same bits
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    plan.exec(dev, dev[256:], dev, dev[256:])
+    torch.cuda.synchronize()
+    o = dev.cpu().numpy().reshape(batch, 2, 256)
+    assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16)) and np.array_equal(o[:, 1].view(np.uint16), gi.view(np.uint16))
+    d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
+    o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
+    tf.TfftPlan(256, batch, 0, in_batch_stride=256, out_batch_stride=256).exec(d_re, d_im, o_re, o_im)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_re.cpu().numpy().view(np.uint16).reshape(batch, 256), gr.view(np.uint16))
+
+
 def test_n4096_known_answers(tf, torch):
     n = 4096
     z = np.zeros((4, n), dtype=np.float16)
