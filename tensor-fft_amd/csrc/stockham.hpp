@@ -129,17 +129,20 @@ struct PassArgs {
   uint32_t inner_shift;  // log2(inner): flattened index = index * inner + c (FFT along a strided axis)
   uint32_t skip_tw;      // the previous pass already applied this pass's input twiddles
   uint64_t tw_mul;       // N / (Ns * R): exponent of w_N per unit of i*k
-  uint64_t blocks_per_fft;
+  uint64_t batch;
+  uint32_t m_shift;      // log2(m_f)
   const float2* tw_lo;   // w_N^e, e < min(N, 8192)
   const float2* tw_hi;   // w_N^(e * 8192), e < N / 8192 (unused when N <= 8192)
 };
 
 template <int R>
 __global__ __launch_bounds__(kBlock) void pass_kernel(PassArgs a) {
-  const uint64_t fft = blockIdx.x / a.blocks_per_fft;
-  const uint64_t j = (blockIdx.x % a.blocks_per_fft) * kBlock + threadIdx.x;
+  // (transform, butterfly) flattened into one index so that short transforms still fill their blocks
+  const uint64_t gid = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x;
   const uint64_t m = a.m_f;
-  if (j >= m) return;
+  const uint64_t fft = gid >> a.m_shift;
+  if (fft >= a.batch) return;
+  const uint64_t j = gid & (m - 1);
   const uint64_t k = j & (a.ns - 1);           // flattened k
   const _Float16* xr = a.in_re + fft * a.in_stride + j;
   const _Float16* xi = a.in_im + fft * a.in_stride + j;
@@ -164,6 +167,52 @@ __global__ __launch_bounds__(kBlock) void pass_kernel(PassArgs a) {
   const float sc = 1.0f / R;
   _Float16* yr = a.out_re + fft * a.out_stride + (j - k) * R + k;
   _Float16* yi = a.out_im + fft * a.out_stride + (j - k) * R + k;
+  if (a.ns == 1) {
+    // first pass of a plain transform: this thread's R outputs are contiguous (y[j R + i]): one or two wide stores
+    typedef _Float16 hvR __attribute__((ext_vector_type(R)));
+    hvR pr, pi;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      pr[i] = static_cast<_Float16>(v[i].re * sc);
+      pi[i] = static_cast<_Float16>(v[i].im * sc);
+    }
+    *reinterpret_cast<hvR*>(yr) = pr;
+    *reinterpret_cast<hvR*>(yi) = pi;
+    return;
+  }
+  if (R == 16 && a.ns == 16) {
+    // second radix-16 pass: the 16 threads of a lane group own the 16 x 16 block y[base + i 16 + k] column by
+    // column (thread = k). Transpose it through LDS (the group lives in one wave, so LDS program order is
+    // enough) and let thread t store row i = t: 32 contiguous bytes per plane instead of 16 two-byte stores.
+    __shared__ uint32_t xchg[kBlock * 16];
+    const uint32_t t = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    uint32_t* mine = xchg + grp * 256 + t * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
+      const hv2 pair = {static_cast<_Float16>(v[i].re * sc), static_cast<_Float16>(v[i].im * sc)};
+      mine[i] = __builtin_bit_cast(uint32_t, pair);
+    }
+    uint32_t row[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) row[kk] = xchg[grp * 256 + kk * 16 + t];
+    typedef uint32_t uv4 __attribute__((ext_vector_type(4)));
+    uv4 re0, re1, im0, im1;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      re0[w] = (row[2 * w] & 0xffffu) | (row[2 * w + 1] << 16);
+      im0[w] = (row[2 * w] >> 16) | (row[2 * w + 1] & 0xffff0000u);
+      re1[w] = (row[8 + 2 * w] & 0xffffu) | (row[8 + 2 * w + 1] << 16);
+      im1[w] = (row[8 + 2 * w] >> 16) | (row[8 + 2 * w + 1] & 0xffff0000u);
+    }
+    _Float16* br = a.out_re + fft * a.out_stride + (j - k) * 16 + t * 16;   // (j - k) is the group's first j
+    _Float16* bi = a.out_im + fft * a.out_stride + (j - k) * 16 + t * 16;
+    reinterpret_cast<uv4*>(br)[0] = re0;
+    reinterpret_cast<uv4*>(br)[1] = re1;
+    reinterpret_cast<uv4*>(bi)[0] = im0;
+    reinterpret_cast<uv4*>(bi)[1] = im1;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     yr[i * a.ns] = static_cast<_Float16>(v[i].re * sc);

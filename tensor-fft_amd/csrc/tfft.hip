@@ -202,7 +202,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
 
 template <int R>
 void launch_pass(const stockham::PassArgs& a, uint64_t batch, hipStream_t s) {
-  const uint64_t grid = a.blocks_per_fft * batch;
+  const uint64_t grid = (a.m_f * batch + stockham::kBlock - 1) / stockham::kBlock;
   hipLaunchKernelGGL(stockham::pass_kernel<R>, dim3(static_cast<uint32_t>(grid)), dim3(stockham::kBlock), 0,
                      s, a);
 }
@@ -222,7 +222,8 @@ void launch_stockham_pass(const tfft_plan* p, const Pass& ps, Planes src, Planes
   a.inner_shift = static_cast<uint32_t>(ilog2(p->inner));
   a.skip_tw = ps.skip_tw ? 1u : 0u;
   a.tw_mul = p->n / (ps.ns * R);
-  a.blocks_per_fft = (a.m_f + stockham::kBlock - 1) / stockham::kBlock;
+  a.batch = p->batch;
+  a.m_shift = static_cast<uint32_t>(ilog2(a.m_f));
   a.tw_lo = p->d_tw_lo;
   a.tw_hi = p->d_tw_hi;
   switch (R) {
