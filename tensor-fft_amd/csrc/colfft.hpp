@@ -57,6 +57,7 @@ struct Args {
   uint64_t n_over_t;                // N / T
   double inv_t;                     // 1 / T
   uint64_t n_mask;                  // N - 1
+  uint32_t copy_only;               // timing experiment (WRONG output): move the image straight back out
   const float2* tw_lo;
   const float2* tw_hi;
   const uint8_t* tables;            // k4096::build_tables blob
@@ -156,6 +157,21 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.copy_only) {
+      // data-movement ceiling of this kernel's access pattern: same 32-byte-per-row pieces out as in
+      uint16_t* const c_re = a.out_re + bidx * a.out_stride + m0;
+      uint16_t* const c_im = a.out_im + bidx * a.out_stride + m0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u4 vr = *reinterpret_cast<const u4*>(wl + i * 1024 + 16 * lane);
+        const u4 vi = *reinterpret_cast<const u4*>(wl + 8192 + i * 1024 + 16 * lane);
+        const uint64_t o = static_cast<uint64_t>(16 * ((lane >> 1) & 15) + (lane >> 5) + 2 * i) * a.pitch + 8 * (lane & 1);
+        *reinterpret_cast<u4*>(c_re + o) = vr;
+        *reinterpret_cast<u4*>(c_im + o) = vi;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      continue;
+    }
 
     // ---- stage 1: D1_ilo[ka = 4g + r][column = lane & 15]
     uint32_t pr[8][4], pi[8][4];
@@ -282,6 +298,212 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
       *reinterpret_cast<u4*>(o_im + o) = vi;
     }
     if (STAGE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image read out before the next copy-in lands on it
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Workgroup-cooperative form: the 8 waves of a workgroup take 8 ADJACENT column groups (128 columns) and move
+// them through one shared LDS image [256 rows][256 bytes] per plane, so that every global access of the
+// workgroup is a full 256-byte row segment (4 rows x 256 B per wave instruction) instead of 32-byte pieces:
+// 4x fewer L2 requests (PMC: the per-wave kernel issues 3x the requests of an autosort pass for the same bytes).
+// 16-byte chunk c of row r lives at slot c ^ (2 ((r >> 4) & 7)) of the row (swizzle applied on the SOURCE
+// address of the LDS-DMA), which makes each wave's transposed reads of its own 32-byte slab conflict free.
+// Needs pitch % 128 == 0; for the columns-in-registers form also ns_f % 128 == 0 (the 128 columns then share
+// `rest` and an output row is 256 contiguous bytes, staged through the same image and stored as full rows).
+// Four workgroup barriers per 128-column block (two in the columns-on-lanes form, whose stores are per wave).
+// ---------------------------------------------------------------------------
+constexpr int kWgPlane = 65536;
+constexpr int kWgLdsBytes = kLdsTable + 2 * kWgPlane;   // 144 KiB
+
+template <int MODE, bool TW>
+__global__ __launch_bounds__(kThreads, 2) void colfft256_wg_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < kLdsTable / 16; i += kThreads)
+    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(a.tables + kOffG)[i];
+  const h8 f_re = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32);
+  const h8 f_im = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32 + 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  uint8_t* const img = lds + kLdsTable;
+  const uint32_t img_off = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)img)));
+  const uint8_t* const g_tab = lds + lane * 16;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, x = lane & 15;
+  // transposed read of tile i_lo by this wave: row r = i_lo + 16 (4g + q), chunk 2 wave + (p >> 1) at slot
+  // chunk ^ 2 ((4g + q) & 7), bytes 8 (p & 1) of it
+  const int ihi = 4 * g + q;
+  const uint8_t* const tr_base = img + (16 * ihi) * 256 + 16 * ((2 * wave + (p >> 1)) ^ (2 * (ihi & 7))) + 8 * (p & 1);
+  // cooperative copy-in / copy-out: wave instruction i of this wave covers rows 32 wave + 4 i .. + 3,
+  // lane -> row + (lane >> 4), slot lane & 15
+  const uint32_t blocks = static_cast<uint32_t>(a.pitch / 128);   // 128-column blocks per batch entry
+  const uint32_t total = blocks * static_cast<uint32_t>(a.tasks / a.groups);
+
+  for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    const uint32_t bidx = blk / blocks;
+    const uint64_t mb = static_cast<uint64_t>(blk - bidx * blocks) * 128;   // first column of the block
+    const uint64_t m0 = mb + 16 * wave;                                     // first column of this wave
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t r = 32 * wave + 4 * i + (lane >> 4);
+      const uint32_t chunk = (lane & 15) ^ (2 * ((r >> 4) & 7));
+      const uint64_t off = (r * a.pitch + mb + 8 * chunk) * 2;
+      const uint8_t* gr = reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off;
+      const uint8_t* gi = reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off;
+      const uint32_t d0 = img_off + (32 * wave + 4 * i) * 256, d1 = d0 + kWgPlane;
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %4\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %2, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+          : "memory");
+    }
+    // twiddle set-up (table look-ups fly with the copy-in), exactly as in the per-wave kernel
+    const uint64_t rest = m0 >> a.ns_f_shift;
+    const uint64_t kprev_f0 = m0 - (rest << a.ns_f_shift);
+    cpx base[4], step = {1.f, 0.f};
+    if (TW) {
+      const uint64_t rest_l = (MODE == kColsOnLanes) ? ((m0 + x) >> a.ns_f_shift) : rest;
+      const uint64_t av = rest_l >> a.a_shift;
+      step = lookup<true>(a, (av * (a.ns & a.t_mask)) & a.t_mask);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t kb = (MODE == kColsOnLanes) ? (4 * g + r) : x;
+        const uint64_t kprev = (MODE == kColsOnLanes)
+                                   ? (((m0 + x) - (rest_l << a.ns_f_shift)) >> a.inner_shift)
+                                   : ((kprev_f0 + 4 * g + r) >> a.inner_shift);
+        base[r] = lookup<true>(a, (av * ((kprev + a.ns * 16 * kb) & a.t_mask)) & a.t_mask);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // A: the whole block is in LDS
+
+    // ---- stage 1
+    uint32_t pr[8][4], pi[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f4 dre[2], dim[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint8_t* ad = tr_base + (2 * t + e) * 256;
+        const s4 xr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad));
+        const s4 xi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad + kWgPlane));
+        const u4 raw = {__builtin_bit_cast(u2, xr).x, __builtin_bit_cast(u2, xr).y,
+                        __builtin_bit_cast(u2, xi).x, __builtin_bit_cast(u2, xi).y};
+        const h8 xv = __builtin_bit_cast(h8, raw);
+        dre[e] = mfma(f_re, xv);
+        dim[e] = mfma(f_im, xv);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[t][r] = pk(dre[0][r], dre[1][r]);
+        pi[t][r] = pk(dim[0][r], dim[1][r]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // B: every wave has read its slab; the image may be overwritten
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        transpose4(pr[0 + pp][r], pr[2 + pp][r], pr[4 + pp][r], pr[6 + pp][r]);
+        transpose4(pi[0 + pp][r], pi[2 + pp][r], pi[4 + pp][r], pi[6 + pp][r]);
+      }
+
+    uint16_t* const o_re = a.out_re + bidx * a.out_stride;
+    uint16_t* const o_im = a.out_im + bidx * a.out_stride;
+    cpx pw = {1.f, 0.f};
+    float hold_re[4], hold_im[4];
+    uint32_t acc_re[4][4], acc_im[4][4];
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) {
+      const int aa = ka >> 2, r0 = ka & 3;
+      const u4 draw = {pr[2 * aa][r0], pr[2 * aa + 1][r0], pi[2 * aa][r0], pi[2 * aa + 1][r0]};
+      const h8 dop = __builtin_bit_cast(h8, draw);
+      const u4 graw = *reinterpret_cast<const u4*>(g_tab + ka * 1024);
+      f4 e_re, e_im;
+      if (MODE == kColsOnLanes) {
+        e_re = mfma(__builtin_bit_cast(h8, graw), dop);
+        e_im = mfma(im_form(graw), dop);
+      } else {
+        e_re = mfma(dop, __builtin_bit_cast(h8, graw));
+        e_im = mfma(dop, im_form(graw));
+      }
+      if (TW) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const cpx w = cmul(base[r], pw);
+          const float vr = e_re[r] * w.re - e_im[r] * w.im;
+          const float vi = e_re[r] * w.im + e_im[r] * w.re;
+          e_re[r] = vr;
+          e_im[r] = vi;
+        }
+        pw = cmul(pw, step);
+      }
+      if (MODE == kColsInRegs) {
+        // row k = ka + 16 kb (kb = x) of the shared output image, this wave's columns 16 wave + 4g .. + 3:
+        // chunk 2 wave + (g >> 1) at slot chunk ^ 2 (kb & 7), bytes 8 (g & 1)
+        const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
+        const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
+        uint8_t* dst = img + (ka + 16 * x) * 256 + 16 * ((2 * wave + (g >> 1)) ^ (2 * (x & 7))) + 8 * (g & 1);
+        *reinterpret_cast<u2*>(dst) = vr;
+        *reinterpret_cast<u2*>(dst + kWgPlane) = vi;
+      } else {
+        if ((ka & 1) == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            hold_re[r] = e_re[r];
+            hold_im[r] = e_im[r];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc_re[r][(ka >> 1) & 3] = pk(hold_re[r], e_re[r]);
+            acc_im[r][(ka >> 1) & 3] = pk(hold_im[r], e_im[r]);
+          }
+          if ((ka & 7) == 7) {
+            const int half = ka >> 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const u4 vr = {acc_re[r][0], acc_re[r][1], acc_re[r][2], acc_re[r][3]};
+              const u4 vi = {acc_im[r][0], acc_im[r][1], acc_im[r][2], acc_im[r][3]};
+              const uint64_t o = (m0 + x) * 256 + 16 * (4 * g + r) + 8 * half;
+              *reinterpret_cast<u4*>(o_re + o) = vr;
+              *reinterpret_cast<u4*>(o_im + o) = vi;
+            }
+          }
+        }
+      }
+    }
+    if (MODE == kColsInRegs) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // C: the output image is complete
+      const uint64_t restb = mb >> a.ns_f_shift;                 // the 128 columns share it (ns_f % 128 == 0)
+      const uint64_t obase = ((restb << 8) << a.ns_f_shift) + (mb - (restb << a.ns_f_shift));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t k = 32 * wave + 4 * i + (lane >> 4);
+        const uint32_t chunk = (lane & 15) ^ (2 * ((k >> 4) & 7));
+        const u4 vr = *reinterpret_cast<const u4*>(img + (32 * wave + 4 * i) * 256 + 16 * lane);
+        const u4 vi = *reinterpret_cast<const u4*>(img + kWgPlane + (32 * wave + 4 * i) * 256 + 16 * lane);
+        const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
+        *reinterpret_cast<u4*>(o_re + o) = vr;
+        *reinterpret_cast<u4*>(o_im + o) = vi;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // D: read out; the next block's copy-in may overwrite the image
+    }
   }
 }
 

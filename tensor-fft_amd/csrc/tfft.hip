@@ -151,6 +151,21 @@ int launch_col_t(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   return TFFT_OK;
 }
 
+template <int MODE, bool TW>
+int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
+  static std::once_flag once[16];
+  hipError_t attr = hipSuccess;
+  std::call_once(once[p->device & 15], [&] {
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_wg_kernel<MODE, TW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWgLdsBytes);
+  });
+  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+  const uint64_t blocks = (a.pitch / 128) * (a.tasks / a.groups);
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
+  hipLaunchKernelGGL((colfft::colfft256_wg_kernel<MODE, TW>), dim3(grid), dim3(k4096::kThreads), colfft::kWgLdsBytes, s, a);
+  return TFFT_OK;
+}
+
 template <bool STAGE, bool LUT>
 int launch_col_s(const tfft_plan* p, const Pass& ps, const colfft::Args& a, hipStream_t s) {
   const bool on_lanes = (a.ns_f == 1);
@@ -179,6 +194,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   a.tw_hi = p->d_tw_hi;
   a.tables = static_cast<const uint8_t*>(p->d_tables);
   a.n_mask = p->n - 1;
+  a.copy_only = (p->variant & 65536) ? 1u : 0u;
   a.a_shift = 0;
   a.t_mask = 0;
   a.n_over_t = 1;
@@ -194,6 +210,13 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   }
   // default: stores straight from registers (8- / 16-byte pieces); variant bit 4096: stage the output through
   // LDS (16-byte coalesced stores). Measured in one process on MI355X: direct wins at 2^16 and 2^20, staging at 2^13.
+  // workgroup-cooperative form (full 256-byte row segments) whenever the geometry allows; variant bit 131072
+  // forces the per-wave kernel
+  const bool wg_ok = (a.pitch % 128 == 0) && (a.ns_f == 1 || a.ns_f % 128 == 0) && !(p->variant & (131072 | 4096 | 8192 | 65536));
+  if (wg_ok) {
+    if (a.ns_f == 1) return ps.tw_next ? launch_col_wg<colfft::kColsOnLanes, true>(p, a, s) : launch_col_wg<colfft::kColsOnLanes, false>(p, a, s);
+    return ps.tw_next ? launch_col_wg<colfft::kColsInRegs, true>(p, a, s) : launch_col_wg<colfft::kColsInRegs, false>(p, a, s);
+  }
   // variant bit 8192: twiddles from v_sin/v_cos instead of the two-level tables
   const bool stage = p->variant & 4096, hw = p->variant & 8192;
   if (stage) return hw ? launch_col_s<true, false>(p, ps, a, s) : launch_col_s<true, true>(p, ps, a, s);
