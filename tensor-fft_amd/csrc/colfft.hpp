@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
 constexpr int kWgPlane = 65536;
 constexpr int kWgLdsBytes = kLdsTable + 2 * kWgPlane;   // 144 KiB
 
-template <int MODE, bool TW>
+template <int MODE, bool TW, bool NT>
 __global__ __launch_bounds__(kThreads, 2) void colfft256_wg_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -356,18 +356,32 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_wg_kernel(Args a) {
       const uint8_t* gi = reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off;
       const uint32_t d0 = img_off + (32 * wave + 4 * i) * 256, d1 = d0 + kWgPlane;
       uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\t"
-          "s_mov_b32 m0, %3\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off\n\t"
-          "s_mov_b32 m0, %4\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %2, off\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
-          : "memory");
+      if (NT)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off nt\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+            : "memory");
+      else
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+            : "memory");
     }
     // twiddle set-up (table look-ups fly with the copy-in), exactly as in the per-wave kernel
     const uint64_t rest = m0 >> a.ns_f_shift;
@@ -498,8 +512,13 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_wg_kernel(Args a) {
         const u4 vr = *reinterpret_cast<const u4*>(img + (32 * wave + 4 * i) * 256 + 16 * lane);
         const u4 vi = *reinterpret_cast<const u4*>(img + kWgPlane + (32 * wave + 4 * i) * 256 + 16 * lane);
         const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
-        *reinterpret_cast<u4*>(o_re + o) = vr;
-        *reinterpret_cast<u4*>(o_im + o) = vi;
+        if (NT) {
+          __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(o_re + o));
+          __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(o_im + o));
+        } else {
+          *reinterpret_cast<u4*>(o_re + o) = vr;
+          *reinterpret_cast<u4*>(o_im + o) = vi;
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();          // D: read out; the next block's copy-in may overwrite the image

@@ -151,18 +151,18 @@ int launch_col_t(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   return TFFT_OK;
 }
 
-template <int MODE, bool TW>
+template <int MODE, bool TW, bool NT>
 int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   static std::once_flag once[16];
   hipError_t attr = hipSuccess;
   std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_wg_kernel<MODE, TW>),
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_wg_kernel<MODE, TW, NT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWgLdsBytes);
   });
   if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint64_t blocks = (a.pitch / 128) * (a.tasks / a.groups);
   const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
-  hipLaunchKernelGGL((colfft::colfft256_wg_kernel<MODE, TW>), dim3(grid), dim3(k4096::kThreads), colfft::kWgLdsBytes, s, a);
+  hipLaunchKernelGGL((colfft::colfft256_wg_kernel<MODE, TW, NT>), dim3(grid), dim3(k4096::kThreads), colfft::kWgLdsBytes, s, a);
   return TFFT_OK;
 }
 
@@ -214,8 +214,13 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   // forces the per-wave kernel
   const bool wg_ok = (a.pitch % 128 == 0) && (a.ns_f == 1 || a.ns_f % 128 == 0) && !(p->variant & (131072 | 4096 | 8192 | 65536));
   if (wg_ok) {
-    if (a.ns_f == 1) return ps.tw_next ? launch_col_wg<colfft::kColsOnLanes, true>(p, a, s) : launch_col_wg<colfft::kColsOnLanes, false>(p, a, s);
-    return ps.tw_next ? launch_col_wg<colfft::kColsInRegs, true>(p, a, s) : launch_col_wg<colfft::kColsInRegs, false>(p, a, s);
+    const bool nt = !(p->variant & 262144);  // non-temporal copy-in and row stores (default; bit 262144 turns them off)
+    if (a.ns_f == 1) {
+      if (nt) return ps.tw_next ? launch_col_wg<colfft::kColsOnLanes, true, true>(p, a, s) : launch_col_wg<colfft::kColsOnLanes, false, true>(p, a, s);
+      return ps.tw_next ? launch_col_wg<colfft::kColsOnLanes, true, false>(p, a, s) : launch_col_wg<colfft::kColsOnLanes, false, false>(p, a, s);
+    }
+    if (nt) return ps.tw_next ? launch_col_wg<colfft::kColsInRegs, true, true>(p, a, s) : launch_col_wg<colfft::kColsInRegs, false, true>(p, a, s);
+    return ps.tw_next ? launch_col_wg<colfft::kColsInRegs, true, false>(p, a, s) : launch_col_wg<colfft::kColsInRegs, false, false>(p, a, s);
   }
   // variant bit 8192: twiddles from v_sin/v_cos instead of the two-level tables
   const bool stage = p->variant & 4096, hw = p->variant & 8192;
@@ -455,10 +460,8 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     need_tables = true;
   } else {
     int n256 = 0;
-    // with >= 256 columns innermost every autosort pass already moves long contiguous runs (measured ~6 TB/s
-    // per radix-16 pass), which beats the column kernel's 32-byte pieces; variant bit 16384 forces the column kernel
-    const bool force_col = opts && (opts->variant & 16384);
-    const bool col_ok = !force_stockham && (inner == 1 ? lg >= 13 : (lg >= 8 && inner >= 16 && (inner < 256 || force_col)));
+    // radix-256 column passes wherever the geometry allows them (variant bit 32 = plain autosort chain)
+    const bool col_ok = !force_stockham && (inner == 1 ? lg >= 13 : (lg >= 8 && inner >= 16));
     if (col_ok) n256 = lg / 8;
     int rem = lg - 8 * n256;
     std::vector<int> radices(n256, 256);
