@@ -247,7 +247,15 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // G and H into LDS, once per (persistent) workgroup.
+  uint8_t* const wl = lds + kLdsTableBytes + wave * kLdsWaveBytes;
+  // LDS byte address of this wave's region (M0 base of its LDS-DMA)
+  const uint32_t wl_off = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)wl)));
+
+  const uint32_t stride_b = gridDim.x * kWavesPerBlock;
+  uint32_t b = blockIdx.x * kWavesPerBlock + wave;
+
+  // G and H into LDS, once per workgroup.
   for (int i = tid; i < kLdsTableBytes / 16; i += kThreads)
     reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(tables + kOffG)[i];
 
@@ -257,11 +265,12 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
   const f4 tw_im = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // table loads retired: vmcnt below counts only loop traffic
   __syncthreads();
+  if (b >= batch) return;
+  // (Issuing this first copy ahead of the table fill was measured 9-20 % SLOWER: workgroups then start their HBM
+  // reads in lock-step. profiles/r1_k4096_grid_scan.txt)
+  dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(b) * in_stride),
+           reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(b) * in_stride), wl_off, lane);
 
-  uint8_t* const wl = lds + kLdsTableBytes + wave * kLdsWaveBytes;
-  // LDS byte address of this wave's region (M0 base of its LDS-DMA)
-  const uint32_t wl_off = __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)wl)));
   const uint8_t* const g_tab = lds + lane * 16;
   const uint8_t* const h_tab = lds + 16384 + lane * 16;
 
@@ -274,11 +283,6 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
   // output geometry: lane (k1 = lane & 15, g) owns k2 = 4 g + r, k0 = 0..15
   const uint32_t out_lane_off = 16u * (lane & 15) + 1024u * g;   // halves, + 256 r + k0
 
-  const uint32_t stride_b = gridDim.x * kWavesPerBlock;
-  uint32_t b = blockIdx.x * kWavesPerBlock + wave;
-  if (b >= batch) return;
-  dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(b) * in_stride),
-         reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(b) * in_stride), wl_off, lane);
   bool first = true;
 
   for (; b < batch; b += stride_b) {

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -78,6 +79,18 @@ struct tfft_plan {
 
 namespace {
 
+// Grid of a grid-stride ("persistent") kernel whose workgroups each own `iters` work items per wave slot: at least one
+// workgroup per CU's worth when there is that much work, otherwise blocks_needed / iters so that the hardware
+// dispatcher hands out workgroups as CUs drain (keeps CUs out of lock-step; see launch_k4096_v).
+inline uint32_t env_iters(const char* name, uint32_t dflt) {
+  const char* e = std::getenv(name);
+  return e ? static_cast<uint32_t>(std::max(0, std::atoi(e))) : dflt;
+}
+inline uint32_t pick_grid(uint64_t blocks_needed, int num_cus, uint32_t iters) {
+  const uint64_t lo = std::min<uint64_t>(blocks_needed, static_cast<uint64_t>(num_cus));
+  return static_cast<uint32_t>(std::max<uint64_t>(lo, (blocks_needed + iters - 1) / std::max(iters, 1u)));
+}
+
 template <int V>
 int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                    uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
@@ -90,7 +103,13 @@ int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, voi
   if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint32_t blocks_needed =
       static_cast<uint32_t>((p->batch + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
-  const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
+  // Workgroups are sized so that each wave runs about two transforms: the second one's HBM->LDS copy flies under
+  // the first one's stores, and the hardware dispatcher hands out the remaining workgroups as CUs drain, which keeps
+  // the CUs out of lock-step (measured: 256 persistent workgroups 5.3 TB/s, two transforms per wave 6.1 TB/s, one
+  // transform per wave 5.1 TB/s; profiles/r1_k4096_grid_scan.txt).
+  static const uint32_t iters_env = env_iters("TFFT_K4096_ITERS", 0);   // experiment knob
+  const uint32_t iters = iters_env ? iters_env : (blocks_needed >= 4u * static_cast<uint32_t>(p->num_cus) ? 2u : 1u);
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
   hipLaunchKernelGGL(k4096::fft4096_kernel<V>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
@@ -109,7 +128,8 @@ int launch_k256(const tfft_plan* p, const void* in_re, const void* in_im, void* 
   if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint64_t groups = (p->batch + k256::kFftsPerWave - 1) / k256::kFftsPerWave;
   const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
-  const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
+  static const uint32_t iters = env_iters("TFFT_K256_ITERS", 2);
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
   hipLaunchKernelGGL(k256::fft256_kernel, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
@@ -146,7 +166,8 @@ int launch_col_t(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   });
   if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint32_t blocks_needed = (a.tasks + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock;
-  const uint32_t grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(p->num_cus));
+  static const uint32_t iters = env_iters("TFFT_COL_ITERS", 1000000);
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
   hipLaunchKernelGGL((colfft::colfft256_kernel<MODE, TW, STAGE, LUT>), dim3(grid), dim3(k4096::kThreads), colfft::kLdsBytes, s, a);
   return TFFT_OK;
 }
@@ -161,7 +182,8 @@ int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   });
   if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint64_t blocks = (a.pitch / 128) * (a.tasks / a.groups);
-  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
+  static const uint32_t iters = env_iters("TFFT_COLWG_ITERS", 1000000);
+  const uint32_t grid = pick_grid(blocks, p->num_cus, iters);
   hipLaunchKernelGGL((colfft::colfft256_wg_kernel<MODE, TW, NT>), dim3(grid), dim3(k4096::kThreads), colfft::kWgLdsBytes, s, a);
   return TFFT_OK;
 }

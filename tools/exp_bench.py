@@ -8,7 +8,7 @@ import __graft_entry__ as g
 g.build()
 import tensor_fft_amd as tf
 
-N, B = 4096, 65536
+N, B = 4096, int(os.environ.get("EXP_BATCH", "65536"))
 variants = [int(v) for v in sys.argv[1:]] or [0]
 x = ((torch.rand(B * 2 * N, device="cuda") * 2 - 1)).to(torch.float16)
 y = torch.empty_like(x)
