@@ -313,16 +313,34 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
 // `rest` and an output row is 256 contiguous bytes, staged through the same image and stored as full rows).
 // Four workgroup barriers per 128-column block (two in the columns-on-lanes form, whose stores are per wave).
 // ---------------------------------------------------------------------------
-constexpr int kWgPlane = 65536;
-constexpr int kWgLdsBytes = kLdsTable + 2 * kWgPlane;   // 144 KiB
+// W = waves per workgroup (8 or 4): a workgroup owns 16 W adjacent columns; the image of a plane is 256 rows of
+// 32 W bytes, addressed as "super-rows" of 256 bytes (= one row for W = 8, two rows for W = 4) so that the same
+// 16-slot swizzle keeps the transposed reads conflict free. With W = 4 a workgroup needs 80 KiB and two of them
+// share a CU: one loads or stores while the other computes (a single 8-wave workgroup runs its copy-in, compute
+// and store phases strictly one after the other, with nothing in flight during the compute phase).
+template <int W>
+struct WgGeom {
+  static constexpr int kThreadsW = 64 * W;
+  static constexpr int kRowBytes = 32 * W;            // one image row of one plane
+  static constexpr int kRps = 8 / W;                  // rows per 256-byte super-row
+  static constexpr int kCpr = 2 * W;                  // 16-byte chunks per row
+  static constexpr int kPlane = 256 * kRowBytes;      // 64 KiB (W = 8) / 32 KiB (W = 4)
+  static constexpr int kLds = kLdsTable + 2 * kPlane; // 144 KiB / 80 KiB
+  static constexpr int kCols = 16 * W;
+};
+constexpr int kWgLdsBytes = WgGeom<8>::kLds;
 
-template <int MODE, bool TW, bool NT>
-__global__ __launch_bounds__(kThreads, 2) void colfft256_wg_kernel(Args a) {
+// STG (columns-on-lanes form only): stage a wave's 16 output rows (one per column, 512 contiguous bytes each)
+// through its own 8-KiB slice of the image and store them as full rows, instead of 16-byte pieces from registers.
+template <int MODE, bool TW, bool NT, int W, bool STG = false>
+__global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
+  using G = WgGeom<W>;
+  constexpr int kPlane = G::kPlane, kRps = G::kRps, kCpr = G::kCpr;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < kLdsTable / 16; i += kThreads)
+  for (int i = tid; i < kLdsTable / 16; i += G::kThreadsW)
     reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(a.tables + kOffG)[i];
   const h8 f_re = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32);
   const h8 f_im = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32 + 16);
@@ -334,27 +352,33 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_wg_kernel(Args a) {
       static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)img)));
   const uint8_t* const g_tab = lds + lane * 16;
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, x = lane & 15;
-  // transposed read of tile i_lo by this wave: row r = i_lo + 16 (4g + q), chunk 2 wave + (p >> 1) at slot
-  // chunk ^ 2 ((4g + q) & 7), bytes 8 (p & 1) of it
+  // Image addressing: row r, 16-byte chunk c (of this workgroup's 2 W chunks) lives in super-row r / kRps at slot
+  // ((r % kRps) kCpr + c) ^ 2 ((r >> 4) & 7). Transposed read of tile row i_lo by this wave: row r = i_lo + 16 ihi
+  // (ihi = 4g + q), chunk 2 wave + (p >> 1), bytes 8 (p & 1) of it; tr_base[h] serves the rows with r % kRps == h.
   const int ihi = 4 * g + q;
-  const uint8_t* const tr_base = img + (16 * ihi) * 256 + 16 * ((2 * wave + (p >> 1)) ^ (2 * (ihi & 7))) + 8 * (p & 1);
-  // cooperative copy-in / copy-out: wave instruction i of this wave covers rows 32 wave + 4 i .. + 3,
-  // lane -> row + (lane >> 4), slot lane & 15
-  const uint32_t blocks = static_cast<uint32_t>(a.pitch / 128);   // 128-column blocks per batch entry
+  const uint8_t* tr_base[kRps];
+#pragma unroll
+  for (int h = 0; h < kRps; ++h)
+    tr_base[h] = img + (16 / kRps) * ihi * 256 + 16 * ((h * kCpr + 2 * wave + (p >> 1)) ^ (2 * (ihi & 7))) + 8 * (p & 1);
+  // cooperative copy-in / copy-out: wave instruction i of this wave covers the 1024 LDS bytes at
+  // 8192 wave + 1024 i (4 super-rows); lane -> super-row + (lane >> 4), slot lane & 15
+  const uint32_t blocks = static_cast<uint32_t>(a.pitch / G::kCols);   // column blocks per batch entry
   const uint32_t total = blocks * static_cast<uint32_t>(a.tasks / a.groups);
 
   for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
     const uint32_t bidx = blk / blocks;
-    const uint64_t mb = static_cast<uint64_t>(blk - bidx * blocks) * 128;   // first column of the block
-    const uint64_t m0 = mb + 16 * wave;                                     // first column of this wave
+    const uint64_t mb = static_cast<uint64_t>(blk - bidx * blocks) * G::kCols;   // first column of the block
+    const uint64_t m0 = mb + 16 * wave;                                          // first column of this wave
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const uint32_t r = 32 * wave + 4 * i + (lane >> 4);
-      const uint32_t chunk = (lane & 15) ^ (2 * ((r >> 4) & 7));
+      const uint32_t sr = 32 * wave + 4 * i + (lane >> 4);
+      const uint32_t v = (lane & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
+      const uint32_t r = sr * kRps + v / kCpr;
+      const uint32_t chunk = v % kCpr;
       const uint64_t off = (r * a.pitch + mb + 8 * chunk) * 2;
       const uint8_t* gr = reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off;
       const uint8_t* gi = reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off;
-      const uint32_t d0 = img_off + (32 * wave + 4 * i) * 256, d1 = d0 + kWgPlane;
+      const uint32_t d0 = img_off + 8192 * wave + 1024 * i, d1 = d0 + kPlane;
       uint32_t keep;
       if (NT)
         asm volatile(
@@ -410,9 +434,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_wg_kernel(Args a) {
       f4 dre[2], dim[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const uint8_t* ad = tr_base + (2 * t + e) * 256;
+        const int i_lo = 2 * t + e;
+        const uint8_t* ad = tr_base[i_lo % kRps] + (i_lo / kRps) * 256;
         const s4 xr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad));
-        const s4 xi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad + kWgPlane));
+        const s4 xi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad + kPlane));
         const u4 raw = {__builtin_bit_cast(u2, xr).x, __builtin_bit_cast(u2, xr).y,
                         __builtin_bit_cast(u2, xi).x, __builtin_bit_cast(u2, xi).y};
         const h8 xv = __builtin_bit_cast(h8, raw);
@@ -467,12 +492,13 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_wg_kernel(Args a) {
       }
       if (MODE == kColsInRegs) {
         // row k = ka + 16 kb (kb = x) of the shared output image, this wave's columns 16 wave + 4g .. + 3:
-        // chunk 2 wave + (g >> 1) at slot chunk ^ 2 (kb & 7), bytes 8 (g & 1)
+        // chunk 2 wave + (g >> 1), bytes 8 (g & 1) of it
         const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
         const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
-        uint8_t* dst = img + (ka + 16 * x) * 256 + 16 * ((2 * wave + (g >> 1)) ^ (2 * (x & 7))) + 8 * (g & 1);
+        uint8_t* dst = img + ((ka / kRps) + (16 / kRps) * x) * 256 +
+                       16 * (((ka % kRps) * kCpr + 2 * wave + (g >> 1)) ^ (2 * (x & 7))) + 8 * (g & 1);
         *reinterpret_cast<u2*>(dst) = vr;
-        *reinterpret_cast<u2*>(dst + kWgPlane) = vi;
+        *reinterpret_cast<u2*>(dst + kPlane) = vi;
       } else {
         if ((ka & 1) == 0) {
 #pragma unroll
@@ -492,25 +518,54 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_wg_kernel(Args a) {
             for (int r = 0; r < 4; ++r) {
               const u4 vr = {acc_re[r][0], acc_re[r][1], acc_re[r][2], acc_re[r][3]};
               const u4 vi = {acc_im[r][0], acc_im[r][1], acc_im[r][2], acc_im[r][3]};
-              const uint64_t o = (m0 + x) * 256 + 16 * (4 * g + r) + 8 * half;
-              *reinterpret_cast<u4*>(o_re + o) = vr;
-              *reinterpret_cast<u4*>(o_im + o) = vi;
+              if (STG) {
+                // image row 16 wave + x (512 B), 16-byte chunk c = 2 (4g + r) + half at slot c ^ x
+                uint8_t* dst = img + 8192 * wave + 512 * x + 16 * ((2 * (4 * g + r) + half) ^ x);
+                *reinterpret_cast<u4*>(dst) = vr;
+                *reinterpret_cast<u4*>(dst + kPlane) = vi;
+              } else {
+                const uint64_t o = (m0 + x) * 256 + 16 * (4 * g + r) + 8 * half;
+                *reinterpret_cast<u4*>(o_re + o) = vr;
+                *reinterpret_cast<u4*>(o_im + o) = vi;
+              }
             }
           }
         }
       }
     }
+    if (MODE == kColsOnLanes && STG) {
+      // the slice is private to this wave (it is also exactly the LDS range of this wave's next copy-in): no barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t f = 2 * i + (lane >> 5);                 // column within the wave's 16
+        const uint32_t chunk = (lane & 31) ^ f;
+        const u4 vr = *reinterpret_cast<const u4*>(img + 8192 * wave + 1024 * i + 16 * lane);
+        const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 8192 * wave + 1024 * i + 16 * lane);
+        const uint64_t o = (m0 + f) * 256 + 8 * chunk;
+        if (NT) {
+          __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(o_re + o));
+          __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(o_im + o));
+        } else {
+          *reinterpret_cast<u4*>(o_re + o) = vr;
+          *reinterpret_cast<u4*>(o_im + o) = vi;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read out before this wave's next copy-in lands on the slice
+    }
     if (MODE == kColsInRegs) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();          // C: the output image is complete
-      const uint64_t restb = mb >> a.ns_f_shift;                 // the 128 columns share it (ns_f % 128 == 0)
+      const uint64_t restb = mb >> a.ns_f_shift;                 // the block's columns share it (ns_f % (16 W) == 0)
       const uint64_t obase = ((restb << 8) << a.ns_f_shift) + (mb - (restb << a.ns_f_shift));
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const uint32_t k = 32 * wave + 4 * i + (lane >> 4);
-        const uint32_t chunk = (lane & 15) ^ (2 * ((k >> 4) & 7));
-        const u4 vr = *reinterpret_cast<const u4*>(img + (32 * wave + 4 * i) * 256 + 16 * lane);
-        const u4 vi = *reinterpret_cast<const u4*>(img + kWgPlane + (32 * wave + 4 * i) * 256 + 16 * lane);
+        const uint32_t sr = 32 * wave + 4 * i + (lane >> 4);
+        const uint32_t v = (lane & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
+        const uint32_t k = sr * kRps + v / kCpr;
+        const uint32_t chunk = v % kCpr;
+        const u4 vr = *reinterpret_cast<const u4*>(img + 8192 * wave + 1024 * i + 16 * lane);
+        const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 8192 * wave + 1024 * i + 16 * lane);
         const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
         if (NT) {
           __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(o_re + o));

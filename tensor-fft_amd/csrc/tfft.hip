@@ -172,20 +172,38 @@ int launch_col_t(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   return TFFT_OK;
 }
 
-template <int MODE, bool TW, bool NT>
+template <int MODE, bool TW, bool NT, int W, bool STG = false>
 int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
+  using G = colfft::WgGeom<W>;
   static std::once_flag once[16];
   hipError_t attr = hipSuccess;
   std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_wg_kernel<MODE, TW, NT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWgLdsBytes);
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds);
   });
   if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
-  const uint64_t blocks = (a.pitch / 128) * (a.tasks / a.groups);
+  const uint64_t blocks = (a.pitch / G::kCols) * (a.tasks / a.groups);
   static const uint32_t iters = env_iters("TFFT_COLWG_ITERS", 1000000);
-  const uint32_t grid = pick_grid(blocks, p->num_cus, iters);
-  hipLaunchKernelGGL((colfft::colfft256_wg_kernel<MODE, TW, NT>), dim3(grid), dim3(k4096::kThreads), colfft::kWgLdsBytes, s, a);
+  const uint32_t grid = pick_grid(blocks, p->num_cus * (8 / W), iters);
+  hipLaunchKernelGGL((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid), dim3(G::kThreadsW), G::kLds, s, a);
   return TFFT_OK;
+}
+
+template <int MODE, bool TW, int W>
+int launch_col_wg_nt(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
+  // non-temporal copy-in and row stores (default; variant bit 262144 turns them off)
+  if (MODE == colfft::kColsOnLanes && !(p->variant & 1048576))   // staged full-row stores (bit 1048576: direct 16-byte pieces)
+    return (p->variant & 262144) ? launch_col_wg<MODE, TW, false, W, true>(p, a, s) : launch_col_wg<MODE, TW, true, W, true>(p, a, s);
+  return (p->variant & 262144) ? launch_col_wg<MODE, TW, false, W>(p, a, s) : launch_col_wg<MODE, TW, true, W>(p, a, s);
+}
+
+template <int W>
+int launch_col_wg_w(const tfft_plan* p, const Pass& ps, const colfft::Args& a, hipStream_t s) {
+  if (a.ns_f == 1)
+    return ps.tw_next ? launch_col_wg_nt<colfft::kColsOnLanes, true, W>(p, a, s)
+                      : launch_col_wg_nt<colfft::kColsOnLanes, false, W>(p, a, s);
+  return ps.tw_next ? launch_col_wg_nt<colfft::kColsInRegs, true, W>(p, a, s)
+                    : launch_col_wg_nt<colfft::kColsInRegs, false, W>(p, a, s);
 }
 
 template <bool STAGE, bool LUT>
@@ -234,16 +252,13 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   // LDS (16-byte coalesced stores). Measured in one process on MI355X: direct wins at 2^16 and 2^20, staging at 2^13.
   // workgroup-cooperative form (full 256-byte row segments) whenever the geometry allows; variant bit 131072
   // forces the per-wave kernel
-  const bool wg_ok = (a.pitch % 128 == 0) && (a.ns_f == 1 || a.ns_f % 128 == 0) && !(p->variant & (131072 | 4096 | 8192 | 65536));
-  if (wg_ok) {
-    const bool nt = !(p->variant & 262144);  // non-temporal copy-in and row stores (default; bit 262144 turns them off)
-    if (a.ns_f == 1) {
-      if (nt) return ps.tw_next ? launch_col_wg<colfft::kColsOnLanes, true, true>(p, a, s) : launch_col_wg<colfft::kColsOnLanes, false, true>(p, a, s);
-      return ps.tw_next ? launch_col_wg<colfft::kColsOnLanes, true, false>(p, a, s) : launch_col_wg<colfft::kColsOnLanes, false, false>(p, a, s);
-    }
-    if (nt) return ps.tw_next ? launch_col_wg<colfft::kColsInRegs, true, true>(p, a, s) : launch_col_wg<colfft::kColsInRegs, false, true>(p, a, s);
-    return ps.tw_next ? launch_col_wg<colfft::kColsInRegs, true, false>(p, a, s) : launch_col_wg<colfft::kColsInRegs, false, false>(p, a, s);
-  }
+  const bool wg_allowed = !(p->variant & (131072 | 4096 | 8192 | 65536));
+  const bool wg8_ok = (a.pitch % 128 == 0) && (a.ns_f == 1 || a.ns_f % 128 == 0);
+  const bool wg4_ok = (a.pitch % 64 == 0) && (a.ns_f == 1 || a.ns_f % 64 == 0);
+  // variant bit 524288: 4-wave workgroups (two per CU) instead of one 8-wave workgroup
+  static const uint32_t wg4_max_pitch = env_iters("TFFT_WG4_MAX_PITCH", 1024);   // experiment knob
+  if (wg_allowed && wg4_ok && ((p->variant & 524288) || !wg8_ok || a.pitch <= wg4_max_pitch)) return launch_col_wg_w<4>(p, ps, a, s);
+  if (wg_allowed && wg8_ok) return launch_col_wg_w<8>(p, ps, a, s);
   // variant bit 8192: twiddles from v_sin/v_cos instead of the two-level tables
   const bool stage = p->variant & 4096, hw = p->variant & 8192;
   if (stage) return hw ? launch_col_s<true, false>(p, ps, a, s) : launch_col_s<true, true>(p, ps, a, s);
