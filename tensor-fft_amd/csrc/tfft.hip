@@ -18,6 +18,7 @@
 
 #include "k4096.hpp"
 #include "k256.hpp"
+#include "k256r.hpp"
 #include "colfft.hpp"
 #include "permute.hpp"
 #include "stockham.hpp"
@@ -46,7 +47,7 @@ inline int ilog2(uint64_t x) {
   return l;
 }
 
-enum class PassKind { K4096, K256, Col256, Stockham };
+enum class PassKind { K4096, K256, K256R, Col256, Stockham };
 
 struct Pass {
   PassKind kind;
@@ -78,6 +79,12 @@ struct tfft_plan {
 };
 
 namespace {
+
+// plans that are one LDS-resident kernel (no ping-pong chain, no workspace, no autosort twiddle tables)
+inline bool single_kernel(const tfft_plan* p) {
+  return p->passes.size() == 1 && (p->passes[0].kind == PassKind::K4096 || p->passes[0].kind == PassKind::K256 ||
+                                   p->passes[0].kind == PassKind::K256R);
+}
 
 // Grid of a grid-stride ("persistent") kernel whose workgroups each own `iters` work items per wave slot: at least one
 // workgroup per CU's worth when there is that much work, otherwise blocks_needed / iters so that the hardware
@@ -135,6 +142,36 @@ int launch_k256(const tfft_plan* p, const void* in_re, const void* in_im, void* 
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
                      static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
   return TFFT_OK;
+}
+
+template <int R>
+int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                   uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
+  static std::once_flag once[16];
+  hipError_t attr = hipSuccess;
+  std::call_once(once[p->device & 15], [&] {
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k256r::fft256r_kernel<R>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, k256r::lds_bytes<R>());
+  });
+  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+  const uint64_t groups = (p->batch + (16 / R) - 1) / (16 / R);
+  const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
+  static const uint32_t iters = env_iters("TFFT_K256_ITERS", 2);
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
+  hipLaunchKernelGGL(k256r::fft256r_kernel<R>, dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
+                     static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
+  return TFFT_OK;
+}
+
+int launch_k256r(const tfft_plan* p, int radix, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                 uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
+  switch (radix) {
+    case 2: return launch_k256r_t<2>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
+    case 4: return launch_k256r_t<4>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
+    default: return launch_k256r_t<8>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
+  }
 }
 
 int launch_k4096(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
@@ -316,10 +353,14 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
                  hipStream_t s) {
   int np = static_cast<int>(p->passes.size());
   if ((p->variant >> 8) & 15) np = std::min(np, (p->variant >> 8) & 15);   // debugging aid: run only the first passes
-  if (np == 1 && (p->passes[0].kind == PassKind::K4096 || p->passes[0].kind == PassKind::K256)) {
-    const int rc = p->passes[0].kind == PassKind::K4096
+  if (single_kernel(p)) {
+    const PassKind kind = p->passes[0].kind;
+    const int rc = kind == PassKind::K4096
                        ? launch_k4096(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s)
-                       : launch_k256(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s);
+                       : (kind == PassKind::K256
+                              ? launch_k256(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s)
+                              : launch_k256r(p, p->passes[0].radix, in_re, in_im, out_re, out_im, p->in_stride,
+                                             p->out_stride, s));
     if (rc) return rc;
     TFFT_HIP(hipGetLastError());
     return TFFT_OK;
@@ -495,6 +536,15 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
   } else if (n == 256 && inner == 1 && !force_stockham) {
     p->passes.push_back(Pass{PassKind::K256, 256, 1, false, false, 0});
     need_tables = true;
+  } else if ((n == 512 || n == 1024 || n == 2048) && inner == 1 && !force_stockham) {
+    const int R = static_cast<int>(n / 256);
+    p->passes.push_back(Pass{PassKind::K256R, R, 1, false, false, 0});
+    std::vector<uint8_t> blob;
+    k256r::build_tables(R, blob);
+    e = hipMalloc(&p->d_tables, blob.size());
+    if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(tables)"));
+    e = hipMemcpy(p->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tables)"));
   } else {
     int n256 = 0;
     // radix-256 column passes wherever the geometry allows them (variant bit 32 = plain autosort chain)
@@ -527,7 +577,7 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     e = hipMemcpy(p->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tables)"));
   }
-  if (!(p->passes.size() == 1 && (p->passes[0].kind == PassKind::K4096 || p->passes[0].kind == PassKind::K256))) {
+  if (!single_kernel(p)) {
     const uint64_t lo_n = std::min<uint64_t>(n, stockham::kTwLoSize);
     const uint64_t hi_n = n > stockham::kTwLoSize ? n / stockham::kTwLoSize : 0;
     std::vector<float2> lo(lo_n), hi(hi_n);
@@ -572,7 +622,7 @@ int tfft_plan_num_launches(const tfft_plan* p) { return p ? static_cast<int>(p->
 size_t tfft_plan_workspace_bytes(const tfft_plan* p) {
   if (!p || p->passes.size() == 1) {
     // a single pass needs scratch only when asked to run in place
-    if (!p || p->passes[0].kind == PassKind::K4096 || p->passes[0].kind == PassKind::K256) return 0;
+    if (!p || single_kernel(p)) return 0;
   }
   return static_cast<size_t>(p->batch) * p->n * p->inner * 4;   // [batch][RE | IM] halves
 }
@@ -664,6 +714,7 @@ const char* tfft_plan_kernel_name(const tfft_plan* p) {
   switch (p->passes[0].kind) {
     case PassKind::K4096: return "fft4096_kernel";
     case PassKind::K256: return "fft256_kernel";
+    case PassKind::K256R: return "fft256r_kernel";
     case PassKind::Col256: return "colfft256_kernel";
     default: return "pass_kernel";
   }
@@ -680,7 +731,7 @@ double tfft_plan_mfma_flops(const tfft_plan* p) {
   // one radix-16 MFMA stage = 16 tiles x 2 MFMA(16x16x32) x 16384 flop per 4096 samples = 128 flop/sample
   double stages = 0;
   for (const Pass& ps : p->passes)
-    stages += ps.kind == PassKind::K4096 ? 3 : ((ps.kind == PassKind::Col256 || ps.kind == PassKind::K256) ? 2 : 0);
+    stages += ps.kind == PassKind::K4096 ? 3 : ((ps.kind == PassKind::Col256 || ps.kind == PassKind::K256 || ps.kind == PassKind::K256R) ? 2 : 0);
   return 128.0 * stages * static_cast<double>(p->n) * static_cast<double>(p->inner) * static_cast<double>(p->batch);
 }
 

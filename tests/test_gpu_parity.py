@@ -229,6 +229,43 @@ def test_n4096_full_size_config(tf, torch, orc):
     _check_against_oracle(orc, re, im, g[:, 0], g[:, 1], mode=orc.MODE_4096)
 
 
+@pytest.mark.parametrize("n", [512, 1024, 2048])
+@pytest.mark.parametrize("batch", [1, 3, 9, 130, 1000])
+def test_n256r_single_pass_kernel(tf, torch, orc, n, batch):
+    """N = 512 / 1024 / 2048 (the reference's TensorFFT256 + radix-2 steps) run as ONE kernel: 16 * 256 / N transforms
+    per wave, ragged last group, strides, in place; an impulse at every position exercises each (n0, n1, r) path."""
+    rng = np.random.default_rng(n + batch)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    plan = tf.TfftPlan(n, batch, 0)
+    assert plan.kernel_name == "fft256r_kernel" and plan.num_launches == 1 and plan.workspace_bytes == 0
+    gr, gi = _run(tf, torch, re, im)
+    _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_256)
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    plan.exec(dev, dev[n:], dev, dev[n:])
+    torch.cuda.synchronize()
+    o = dev.cpu().numpy().reshape(batch, 2, n)
+    assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16)) and np.array_equal(o[:, 1].view(np.uint16), gi.view(np.uint16))
+    d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
+    o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
+    tf.TfftPlan(n, batch, 0, in_batch_stride=n, out_batch_stride=n).exec(d_re, d_im, o_re, o_im)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_re.cpu().numpy().reshape(batch, n).view(np.uint16), gr.view(np.uint16))
+    assert np.array_equal(o_im.cpu().numpy().reshape(batch, n).view(np.uint16), gi.view(np.uint16))
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048])
+def test_n256r_impulse_at_every_position(tf, torch, n):
+    """x = N * delta[n - p] for every p: X[k] = exp(-2 pi i p k / N) exactly representable inputs, every sample path."""
+    re = (np.eye(n, dtype=np.float64) * 1024.0).astype(np.float16)      # batch = n transforms, impulse p in transform p
+    im = np.zeros_like(re)
+    gr, gi = _run(tf, torch, re, im)
+    k = np.arange(n)
+    want = np.exp(-2j * np.pi * np.outer(k, k) / n) * (1024.0 / n)
+    got = gr.astype(np.float64) + 1j * gi.astype(np.float64)
+    assert np.abs(got - want).max() <= 2.5e-3 * (1024.0 / n) + 2.0 ** -11 * (1024.0 / n)
+
+
 @pytest.mark.parametrize("lg", [1, 2, 3, 4, 5, 8, 9, 10, 11, 13, 14, 15, 16])
 def test_generic_lengths(tf, torch, orc, lg):
     n = 1 << lg
