@@ -332,6 +332,8 @@ void launch_stockham_pass(const tfft_plan* p, const Pass& ps, Planes src, Planes
     case 2: launch_pass<2>(a, p->batch, s); break;
     case 4: launch_pass<4>(a, p->batch, s); break;
     case 8: launch_pass<8>(a, p->batch, s); break;
+    case 32: launch_pass<32>(a, p->batch, s); break;
+    case 64: launch_pass<64>(a, p->batch, s); break;
     default: launch_pass<16>(a, p->batch, s); break;
   }
 }
@@ -554,6 +556,16 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     std::vector<int> radices(n256, 256);
     for (; rem >= 4; rem -= 4) radices.push_back(16);
     if (rem) radices.push_back(1 << rem);
+    // a radix-16 pass followed by a radix-2 / radix-4 pass behind a column pass fuses into one radix-32 / radix-64
+    // pass (the butterfly fits in registers; its input twiddles come from the column pass). variant bit 2097152 keeps them apart.
+    const bool fuse_tail = !(opts && (opts->variant & 2097152));
+    if (fuse_tail && n256 >= 1 && radices.size() >= static_cast<size_t>(n256) + 2) {
+      const size_t last = radices.size() - 1;
+      if (radices[last - 1] == 16 && (radices[last] == 2 || radices[last] == 4) && last - 1 == static_cast<size_t>(n256)) {
+        radices[last - 1] = 16 * radices[last];
+        radices.pop_back();
+      }
+    }
     uint64_t ns = 1;
     for (size_t i = 0; i < radices.size(); ++i) {
       const int R = radices[i];
