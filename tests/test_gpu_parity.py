@@ -178,6 +178,29 @@ def test_n4096_large_and_tiny_magnitudes(tf, torch, orc):
     assert np.abs(got[1] - exact[1]).max() < 2 * 2.0 ** -24 + 1e-3 * np.abs(exact[1]).max()
 
 
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536])
+def test_full_scale_inputs_do_not_overflow(tf, torch, orc, n):
+    """Every kernel family scales by its radix per stage, so |intermediates| <= max|x|: full-scale constant and
+    alternating inputs (fp16 max = 65504) give the exact DC / Nyquist line, full-scale noise stays finite."""
+    rng = np.random.default_rng(n)
+    re = np.empty((3, n), np.float16)
+    im = np.empty((3, n), np.float16)
+    re[0], im[0] = 65504.0, -65504.0
+    re[1] = 65504.0 * (1 - 2 * (np.arange(n) & 1))
+    im[1] = 0.0
+    re[2] = (rng.uniform(-1, 1, n) * 65504).astype(np.float16)
+    im[2] = (rng.uniform(-1, 1, n) * 65504).astype(np.float16)
+    gr, gi = _run(tf, torch, re, im)
+    got = _c(gr, gi)
+    assert np.isfinite(got).all()
+    want0 = np.zeros(n, complex); want0[0] = 65504.0 - 65504.0j
+    want1 = np.zeros(n, complex); want1[n // 2] = 65504.0
+    assert np.abs(got[0] - want0).max() <= 65504 * 2.0 ** -10
+    assert np.abs(got[1] - want1).max() <= 65504 * 2.0 ** -10
+    exact = _c(*orc.dft64(re[2:], im[2:]))
+    assert np.linalg.norm(got[2] - exact[0]) / np.linalg.norm(exact[0]) < REL_L2_TOL
+
+
 def test_n4096_in_place_and_strides(tf, torch, orc):
     n, batch = 4096, 19
     rng = np.random.default_rng(21)
