@@ -362,22 +362,28 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
     tr_base[h] = img + (16 / kRps) * ihi * 256 + 16 * ((h * kCpr + 2 * wave + (p >> 1)) ^ (2 * (ihi & 7))) + 8 * (p & 1);
   // cooperative copy-in / copy-out: wave instruction i of this wave covers the 1024 LDS bytes at
   // 8192 wave + 1024 i (4 super-rows); lane -> super-row + (lane >> 4), slot lane & 15
-  const uint32_t blocks = static_cast<uint32_t>(a.pitch / G::kCols);   // column blocks per batch entry
-  const uint32_t total = blocks * static_cast<uint32_t>(a.tasks / a.groups);
+  // Column blocks are counted over (batch entry, column) flattened: for pitch >= 16 W a block is 16 W adjacent
+  // columns of one entry; for a narrower pitch (columns-on-lanes form only) it spans 16 W / pitch whole entries,
+  // whose rows are then contiguous in memory (N = 256 pitch), so the copy-in still moves full lines.
+  const uint32_t pshift = static_cast<uint32_t>(__builtin_ctzll(a.pitch));
+  const uint32_t total = static_cast<uint32_t>(((a.tasks / a.groups) << pshift) / G::kCols);
 
   for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
-    const uint32_t bidx = blk / blocks;
-    const uint64_t mb = static_cast<uint64_t>(blk - bidx * blocks) * G::kCols;   // first column of the block
-    const uint64_t m0 = mb + 16 * wave;                                          // first column of this wave
+    const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;        // first flattened column of the block
+    const uint64_t gcw = gc0 + 16 * wave;                              // ... of this wave
+    const uint64_t bidx = gcw >> pshift;                               // this wave's batch entry
+    const uint64_t mb = gc0 & (a.pitch - 1);                           // first column of the block (pitch >= 16 W)
+    const uint64_t m0 = gcw & (a.pitch - 1);                           // first column of this wave
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t sr = 32 * wave + 4 * i + (lane >> 4);
       const uint32_t v = (lane & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
       const uint32_t r = sr * kRps + v / kCpr;
       const uint32_t chunk = v % kCpr;
-      const uint64_t off = (r * a.pitch + mb + 8 * chunk) * 2;
-      const uint8_t* gr = reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off;
-      const uint8_t* gi = reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off;
+      const uint64_t gcol = gc0 + 8 * chunk;
+      const uint64_t off = (r * a.pitch + (gcol & (a.pitch - 1))) * 2;
+      const uint8_t* gr = reinterpret_cast<const uint8_t*>(a.in_re + (gcol >> pshift) * a.in_stride) + off;
+      const uint8_t* gi = reinterpret_cast<const uint8_t*>(a.in_im + (gcol >> pshift) * a.in_stride) + off;
       const uint32_t d0 = img_off + 8192 * wave + 1024 * i, d1 = d0 + kPlane;
       uint32_t keep;
       if (NT)

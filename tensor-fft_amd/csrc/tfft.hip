@@ -219,7 +219,7 @@ int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds);
   });
   if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
-  const uint64_t blocks = (a.pitch / G::kCols) * (a.tasks / a.groups);
+  const uint64_t blocks = (a.tasks / a.groups) * a.pitch / G::kCols;
   static const uint32_t iters = env_iters("TFFT_COLWG_ITERS", 1000000);
   const uint32_t grid = pick_grid(blocks, p->num_cus * (8 / W), iters);
   hipLaunchKernelGGL((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid), dim3(G::kThreadsW), G::kLds, s, a);
@@ -290,11 +290,32 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   // workgroup-cooperative form (full 256-byte row segments) whenever the geometry allows; variant bit 131072
   // forces the per-wave kernel
   const bool wg_allowed = !(p->variant & (131072 | 4096 | 8192 | 65536));
+  const uint64_t entries = a.tasks / a.groups;
+  // narrow pitch (N = 256 pitch contiguous, columns-on-lanes form): a workgroup spans 128 / pitch whole batch
+  // entries; entries that do not fill a workgroup go to the per-wave kernel in a second launch.
+  if (wg_allowed && a.ns_f == 1 && a.pitch >= 16 && a.pitch < 128) {
+    const uint64_t per = 128 / a.pitch;
+    const uint64_t main_entries = entries - entries % per;
+    if (main_entries) {
+      colfft::Args am = a;
+      am.tasks = static_cast<uint32_t>(main_entries * a.groups);
+      const int rc = launch_col_wg_w<8>(p, ps, am, s);
+      if (rc || main_entries == entries) return rc;
+      a.in_re += main_entries * a.in_stride;
+      a.in_im += main_entries * a.in_stride;
+      a.out_re += main_entries * a.out_stride;
+      a.out_im += main_entries * a.out_stride;
+      a.tasks = static_cast<uint32_t>((entries - main_entries) * a.groups);
+    }
+    if (a.pitch % 64 == 0) return launch_col_wg_w<4>(p, ps, a, s);   // 64 columns: one 4-wave workgroup per entry
+    return launch_col_s<false, true>(p, ps, a, s);
+  }
   const bool wg8_ok = (a.pitch % 128 == 0) && (a.ns_f == 1 || a.ns_f % 128 == 0);
   const bool wg4_ok = (a.pitch % 64 == 0) && (a.ns_f == 1 || a.ns_f % 64 == 0);
   // variant bit 524288: 4-wave workgroups (two per CU) instead of one 8-wave workgroup
   static const uint32_t wg4_max_pitch = env_iters("TFFT_WG4_MAX_PITCH", 1024);   // experiment knob
-  if (wg_allowed && wg4_ok && ((p->variant & 524288) || !wg8_ok || a.pitch <= wg4_max_pitch)) return launch_col_wg_w<4>(p, ps, a, s);
+  if (wg_allowed && wg4_ok && ((p->variant & 524288) || !wg8_ok || a.pitch <= wg4_max_pitch))
+    return launch_col_wg_w<4>(p, ps, a, s);
   if (wg_allowed && wg8_ok) return launch_col_wg_w<8>(p, ps, a, s);
   // variant bit 8192: twiddles from v_sin/v_cos instead of the two-level tables
   const bool stage = p->variant & 4096, hw = p->variant & 8192;
@@ -629,6 +650,7 @@ void tfft_plan_destroy(tfft_plan* p) {
   delete p;
 }
 
+// passes over the data (a narrow column pass with a ragged batch takes two launches for its one pass)
 int tfft_plan_num_launches(const tfft_plan* p) { return p ? static_cast<int>(p->passes.size()) : 0; }
 
 size_t tfft_plan_workspace_bytes(const tfft_plan* p) {

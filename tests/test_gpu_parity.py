@@ -317,6 +317,20 @@ def test_generic_lengths(tf, torch, orc, lg):
     assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16))
 
 
+@pytest.mark.parametrize("n,batch", [(8192, 4), (8192, 5), (8192, 7), (8192, 64), (16384, 2), (16384, 3), (16384, 9)])
+def test_narrow_pitch_cooperative_column_pass(tf, torch, orc, n, batch):
+    """N = 2^13 / 2^14: the radix-256 column pass has only 32 / 64 columns; a workgroup takes 4 / 2 whole
+    transforms (contiguous rows); a ragged remainder goes to a second launch. Must equal the per-wave kernel (variant bit 131072)
+    bit for bit, and the oracle within tolerance."""
+    rng = np.random.default_rng(n + batch)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    gr, gi = _run(tf, torch, re, im)
+    pr, pi = _run(tf, torch, re, im, variant=131072)
+    assert np.array_equal(gr.view(np.uint16), pr.view(np.uint16)) and np.array_equal(gi.view(np.uint16), pi.view(np.uint16))
+    _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_256)
+
+
 @pytest.mark.parametrize("lg", [13, 16, 17])
 def test_plain_autosort_chain_still_correct(tf, torch, orc, lg):
     """variant bit 32 forces the radix-2/4/8/16 autosort chain (no radix-256 column kernel)."""
