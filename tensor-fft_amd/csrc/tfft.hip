@@ -289,7 +289,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   // LDS (16-byte coalesced stores). Measured in one process on MI355X: direct wins at 2^16 and 2^20, staging at 2^13.
   // workgroup-cooperative form (full 256-byte row segments) whenever the geometry allows; variant bit 131072
   // forces the per-wave kernel
-  const bool wg_allowed = !(p->variant & (131072 | 4096 | 8192 | 65536));
+  const bool wg_allowed = !(p->variant & (131072 | 4096 | 8192));
   const uint64_t entries = a.tasks / a.groups;
   // narrow pitch (N = 256 pitch contiguous, columns-on-lanes form): a workgroup spans 128 / pitch whole batch
   // entries; entries that do not fill a workgroup go to the per-wave kernel in a second launch.
@@ -314,7 +314,9 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   const bool wg4_ok = (a.pitch % 64 == 0) && (a.ns_f == 1 || a.ns_f % 64 == 0);
   // variant bit 524288: 4-wave workgroups (two per CU) instead of one 8-wave workgroup
   static const uint32_t wg4_max_pitch = env_iters("TFFT_WG4_MAX_PITCH", 1024);   // experiment knob
-  if (wg_allowed && wg4_ok && ((p->variant & 524288) || !wg8_ok || a.pitch <= wg4_max_pitch))
+  // ... also when 8-wave workgroups would leave CUs idle (single long transforms: 2^20 x 1 is 32 blocks of 128 columns)
+  const bool few_blocks = entries * a.pitch / 128 < static_cast<uint64_t>(p->num_cus);
+  if (wg_allowed && wg4_ok && ((p->variant & 524288) || !wg8_ok || a.pitch <= wg4_max_pitch || few_blocks))
     return launch_col_wg_w<4>(p, ps, a, s);
   if (wg_allowed && wg8_ok) return launch_col_wg_w<8>(p, ps, a, s);
   // variant bit 8192: twiddles from v_sin/v_cos instead of the two-level tables
