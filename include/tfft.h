@@ -97,18 +97,25 @@ typedef struct tfft_plan_opts {
                            local passes of a distributed transform) */
   int preserve_input;   /* 0: the input planes may be used as scratch, exactly as the
                            reference does (ComputeFFT.h:89-93,118-119); 1: never written */
-  int variant;          /* tuner knob of the N == 4096 kernel: 0 = default; else a mask of 1 = prefetch the
-                           next transform under stages 2/3, 2 = stage the output through LDS (full-row
-                           stores), 8 = non-temporal loads/stores, 4 = timing-only fake stores (WRONG
-                           results); 16 = none of these; 32 = (any N) plain autosort chain, no column kernel */
+  int variant;          /* tuner / experiment knob, 0 = default (what tools/tuner.py writes as the sixth column).
+                           N == 4096 kernel: mask of 1 = prefetch the next transform under stages 2/3, 2 = stage
+                           the output through LDS (full-row stores), 8 = non-temporal loads/stores, 16 = none of
+                           these (default = 2|8); 4 and 64 are timing-only (WRONG results).
+                           Any N: 32 = plain autosort chain (no column kernel); 2097152 = do not fuse the
+                           radix-16 + radix-2/4 tail into one radix-32/64 pass.
+                           Column passes: 131072 = per-wave kernel, 524288 = 4-wave cooperative workgroups,
+                           262144 = no non-temporal accesses, 1048576 = 16-byte stores straight from registers,
+                           4096 / 8192 = per-wave kernel with LDS-staged stores / hardware sin-cos twiddles.
+                           Debugging aids (WRONG or partial results): (p << 8), p = 1..15: run only the first
+                           p passes; 128 = skip inter-pass twiddles; 65536 = copy-only column pass. */
 } tfft_plan_opts;
 
 int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts,
                      tfft_plan** out);
 void tfft_plan_destroy(tfft_plan* plan);
 
-/* Number of kernel launches one tfft_exec issues and the bytes of device scratch
- * it needs beyond in/out (0 for N == 4096). If nonzero, either hand memory in
+/* Number of passes over the data one tfft_exec makes (= kernel launches, except that a narrow column pass with a
+ * ragged batch takes two) and the bytes of device scratch it needs beyond in/out (0 for N <= 4096). If nonzero, either hand memory in
  * with tfft_plan_set_workspace() or let the first tfft_exec hipMalloc it. */
 int tfft_plan_num_launches(const tfft_plan* plan);
 size_t tfft_plan_workspace_bytes(const tfft_plan* plan);

@@ -557,3 +557,38 @@ def test_cxx_shim_example():
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         print(r.stdout)
         assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_one_plan_from_several_host_threads(tf, torch):
+    """the plan is immutable after creation, so host threads may share it (each on its own stream and
+    buffers). Multi-pass plan with a library-allocated workspace would be shared scratch, so every thread sets none:
+    """
+    import threading
+    n, batch = 4096, 64
+    plan = tf.TfftPlan(n, batch, 0)
+    rng = np.random.default_rng(77)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, batch * 2 * n).astype(np.float16)).cuda() for _ in range(4)]
+    want = []
+    for x in xs:
+        y = torch.empty_like(x)
+        plan.exec(x, x[n:], y, y[n:])
+        torch.cuda.synchronize()
+        want.append(y.clone())
+    got = [torch.zeros_like(x) for x in xs]
+    errs = []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            for _ in range(20):
+                plan.exec(xs[i], xs[i][n:], got[i], got[i][n:], s.cuda_stream)
+            s.synchronize()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs
+    for g_, w_ in zip(got, want):
+        assert bool((g_ == w_).all())

@@ -41,7 +41,9 @@ def main():
         batch = max(1, (1 << args.total_log2) // n)
         x = (torch.rand(batch * 2 * n, device="cuda") * 2 - 1).half()
         y = torch.empty_like(x)
-        cands = [16, 2, 10, 8, 1] if n == 4096 else [0, 32]          # 0 is the same as 10 at N = 4096
+        # 0 = library default (10 at N = 4096); 32 = plain autosort chain; 524288 = 4-wave cooperative column
+        # workgroups; 2097152 = unfused radix-16 + radix-2/4 tail; 1048576 = unstaged column stores
+        cands = [16, 2, 10, 8, 1] if n == 4096 else ([0, 32] if n < 8192 else [0, 32, 524288, 2097152, 1048576])
         best = None
         for v in cands:
             try:
