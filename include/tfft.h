@@ -88,7 +88,10 @@ int tfft_max_no_optin_shared_mem(int device_id);
  * in/out_batch_stride: distance in halves between consecutive FFTs of a plane;
  * 0 selects the DataBatchHandler default 2*n (2*n*inner). Must be a multiple of 8.
  * The plan is immutable after creation and may be shared between host threads;
- * it owns small device-side constant tables (and a workspace if it allocated one). */
+ * it owns small device-side constant tables (and a workspace if it allocated one).
+ * A plan with tfft_plan_workspace_bytes() > 0 has ONE workspace: executions of such a plan
+ * must not overlap in time (same stream, or one plan per stream). Single-pass plans
+ * (N <= 4096 with a contiguous axis) have no such restriction. */
 typedef struct tfft_plan_opts {
   uint64_t in_batch_stride;
   uint64_t out_batch_stride;
