@@ -14,7 +14,8 @@
 //            exchange step at all; w256^(n0 k0) is 4 fp32 constants per lane (the same for every tile).
 //   stage 2  data as A again (rows k0, slots n0), F as B  ->  D2[k0 = 4g + r][k1 = lane & 15]
 //            a lane ends with 4 consecutive outputs k0 = 4g..4g+3 of k = k0 + 16 k1: 8-byte pieces that tile the
-//            transform's 512-byte plane exactly, one wave instruction per transform and plane.
+//            transform's 512-byte plane exactly; they are staged through the transform's LDS slot and leave as
+//            one 1-KiB non-temporal row per transform.
 // No constant tables in LDS (F lives in 8 VGPRs), no inter-wave synchronisation.
 #pragma once
 
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
           "s_mov_b32 %0, m0\n\t"
           "s_mov_b32 m0, %2\n\t"
           "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off\n\t"
+          "global_load_lds_dwordx4 %1, off nt\n\t"
           "s_mov_b32 m0, %0"
           : "=&s"(keep)
           : "v"(src), "s"(d)
@@ -104,12 +105,20 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
       // stage 2: rows k0, slots n0  ->  D2[k0 = 4g + r][k1 = lane & 15]
       const f4 o_re = mfma(a2, f_re);
       const f4 o_im = mfma(a2, f_im);
+      // stage the spectrum in the transform's own (consumed) 1-KiB slot [RE 512 B | IM 512 B] ...
+      const u2 vr = {pk(o_re[0], o_re[1]), pk(o_re[2], o_re[3])};
+      const u2 vi = {pk(o_im[0], o_im[1]), pk(o_im[2], o_im[3])};
+      *reinterpret_cast<u2*>(wl + t * 1024 + 2 * out_lane) = vr;
+      *reinterpret_cast<u2*>(wl + t * 1024 + 512 + 2 * out_lane) = vi;
+    }
+    // ... and store it as one 1-KiB row per transform: lanes 0-31 the RE plane, lanes 32-63 the IM plane, 16-byte
+    // non-temporal stores (+2-4 % over 8-byte pieces straight from registers)
+#pragma unroll
+    for (int t = 0; t < kFftsPerWave; ++t) {
+      const u4 v = *reinterpret_cast<const u4*>(wl + t * 1024 + 16 * lane);
       if (static_cast<uint32_t>(t) < nb) {
-        const uint64_t o = static_cast<uint64_t>(b0 + t) * out_stride + out_lane;
-        const u2 vr = {pk(o_re[0], o_re[1]), pk(o_re[2], o_re[3])};
-        const u2 vi = {pk(o_im[0], o_im[1]), pk(o_im[2], o_im[3])};
-        *reinterpret_cast<u2*>(out_re + o) = vr;
-        *reinterpret_cast<u2*>(out_im + o) = vi;
+        uint16_t* dst = ((lane < 32) ? out_re : out_im) + static_cast<uint64_t>(b0 + t) * out_stride + 8 * (lane & 31);
+        __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image consumed before the next copy-in lands on it

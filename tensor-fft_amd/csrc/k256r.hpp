@@ -103,7 +103,9 @@ inline void build_tables(int R, std::vector<uint8_t>& blob) {
 }
 
 // in_*/out_*: planar binary16; transform b at +b*stride halves. tables: build_tables(R) blob.
-template <int R>
+// STG: stage each transform's spectrum through its own (already consumed) LDS slot and store it as full 1-KiB rows with
+// non-temporal 16-byte stores, instead of 8-byte pieces straight from registers.
+template <int R, bool STG = true>
 __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                               uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
                                                               uint64_t out_stride, uint32_t batch,
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
           "s_mov_b32 %0, m0\n\t"
           "s_mov_b32 m0, %2\n\t"
           "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off\n\t"
+          "global_load_lds_dwordx4 %1, off nt\n\t"
           "s_mov_b32 m0, %0"
           : "=&s"(keep)
           : "v"(src), "s"(d)
@@ -251,7 +253,15 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
           }
         }
       }
-      if (static_cast<uint32_t>(t) < nb) {
+      if (STG) {
+        // the transposed reads of transform t have all returned (their data went through the MFMAs above)
+        uint8_t* const slot = wl + t * 2 * kPlane + 2 * out_lane;
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+          *reinterpret_cast<u2*>(slot + 512 * s) = u2{pk_re[s][0], pk_re[s][1]};
+          *reinterpret_cast<u2*>(slot + kPlane + 512 * s) = u2{pk_im[s][0], pk_im[s][1]};
+        }
+      } else if (static_cast<uint32_t>(t) < nb) {
         const uint64_t o = static_cast<uint64_t>(b0 + t) * out_stride + out_lane;
 #pragma unroll
         for (int s = 0; s < R; ++s) {
@@ -259,6 +269,17 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
           const u2 vi = {pk_im[s][0], pk_im[s][1]};
           *reinterpret_cast<u2*>(out_re + o + 256 * s) = vr;
           *reinterpret_cast<u2*>(out_im + o + 256 * s) = vi;
+        }
+      }
+    }
+    if (STG) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int t = i / R, ii = i % R, plane = ii / (R / 2), pq = ii % (R / 2);
+        const u4 v = *reinterpret_cast<const u4*>(wl + i * 1024 + 16 * lane);
+        if (static_cast<uint32_t>(t) < nb) {
+          uint16_t* dst = (plane ? out_im : out_re) + static_cast<uint64_t>(b0 + t) * out_stride + 512 * pq + 8 * lane;
+          __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
         }
       }
     }

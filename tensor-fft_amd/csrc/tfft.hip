@@ -144,13 +144,13 @@ int launch_k256(const tfft_plan* p, const void* in_re, const void* in_im, void* 
   return TFFT_OK;
 }
 
-template <int R>
+template <int R, bool STG>
 int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                    uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
   static std::once_flag once[16];
   hipError_t attr = hipSuccess;
   std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k256r::fft256r_kernel<R>),
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k256r::fft256r_kernel<R, STG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, k256r::lds_bytes<R>());
   });
   if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
@@ -158,7 +158,7 @@ int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, voi
   const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
   static const uint32_t iters = env_iters("TFFT_K256_ITERS", 2);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
-  hipLaunchKernelGGL(k256r::fft256r_kernel<R>, dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
+  hipLaunchKernelGGL((k256r::fft256r_kernel<R, STG>), dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
                      static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
@@ -167,10 +167,17 @@ int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, voi
 
 int launch_k256r(const tfft_plan* p, int radix, const void* in_re, const void* in_im, void* out_re, void* out_im,
                  uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
+  const bool direct = p->variant & 1048576;   // 8-byte stores straight from registers instead of staged full rows
   switch (radix) {
-    case 2: return launch_k256r_t<2>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
-    case 4: return launch_k256r_t<4>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
-    default: return launch_k256r_t<8>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
+    case 2:
+      return direct ? launch_k256r_t<2, false>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s)
+                    : launch_k256r_t<2, true>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
+    case 4:
+      return direct ? launch_k256r_t<4, false>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s)
+                    : launch_k256r_t<4, true>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
+    default:
+      return direct ? launch_k256r_t<8, false>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s)
+                    : launch_k256r_t<8, true>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
   }
 }
 
