@@ -25,6 +25,9 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
 if "SQ_WAVE_CYCLES" in mean:
     wc = mean["SQ_WAVE_CYCLES"]
     out["wave_time_shares"] = {k: mean[k] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in mean}
+if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs (256 CUs x 4)
+    out["mfma_busy_fraction"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (mean["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 p = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
 json.dump(out, open(p, "w"), indent=1, sort_keys=True)
