@@ -559,10 +559,18 @@ def test_cxx_shim_example():
         assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_cxx_batched_benchmark_driver():
+    """examples/bench_batched.cpp: the C++ counterpart of the reference's FFTBenchBatch.cu over the shim + C ABI."""
+    exe = os.path.join(ROOT, "examples", "bench_batched")
+    for args in (["12", "512", "5", "2"], ["10", "1000", "5", "2"], ["14", "64", "5", "2"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        print(r.stdout)
+        assert r.returncode == 0 and "Gsamples/s" in r.stdout, r.stdout + r.stderr
+
+
 def test_one_plan_from_several_host_threads(tf, torch):
     """the plan is immutable after creation, so host threads may share it (each on its own stream and
-    buffers). Multi-pass plan with a library-allocated workspace would be shared scratch, so every thread sets none:
-    """
+    buffers). N = 4096 is a single-pass plan: no workspace is shared between the threads."""
     import threading
     n, batch = 4096, 64
     plan = tf.TfftPlan(n, batch, 0)
@@ -592,3 +600,22 @@ def test_one_plan_from_several_host_threads(tf, torch):
     assert not errs, errs
     for g_, w_ in zip(got, want):
         assert bool((g_ == w_).all())
+
+
+@pytest.mark.parametrize("lg", [8, 9, 11, 12, 13, 15, 16, 18, 20, 21])
+def test_against_vendor_fft_on_device(tf, torch, lg):
+    """Independent cross-check that needs no CPU oracle: hipFFT (through torch.fft, complex64) on the same fp16 input,
+    the role cuFFT plays in the reference's tests (CuFFTTest.h:193-261). Large N run here in seconds."""
+    n = 1 << lg
+    batch = max(1, (1 << 22) // n)
+    gen = torch.Generator(device="cuda").manual_seed(lg)
+    x = (torch.rand(batch, 2, n, device="cuda", generator=gen) * 2 - 1).half()
+    flat = x.reshape(-1)
+    y = torch.empty_like(flat)
+    tf.TfftPlan(n, batch, 0, preserve_input=True).exec(flat, flat[n:], y, y[n:])
+    want = torch.fft.fft(torch.complex(x[:, 0].float(), x[:, 1].float()), dim=1) / n
+    got = y.reshape(batch, 2, n)
+    got = torch.complex(got[:, 0].float(), got[:, 1].float())
+    rel = float(torch.linalg.vector_norm(got - want) / torch.linalg.vector_norm(want))
+    assert rel <= REL_L2_TOL, rel
+    assert float((got - want).abs().max()) <= 8 * 2.0 ** -11 * float(want.abs().max())
