@@ -13,6 +13,8 @@ Rank 0 prints ONE JSON line. `roofline` is the HBM roofline of the dominant kern
 8 B per complex sample per launch: 4 read + 4 written) with the launch duration measured here
 by HIP events on the launch stream. `cpu_baseline` is the CPU oracle's fp64 FFT (oracle/, a port: the
 reference has no CPU path, its oracle is cuFFT on the GPU) timed on this host's cores on a bounded sample.
+At N=1 GPU a further object `other_configs` carries short measurements of the other BASELINE configs (2^20 x 1024,
+2D 4096^2 x 64, single 2^26) and neighbouring lengths, taken AFTER the timed region; they do not enter `value`.
 """
 import argparse
 import json
@@ -63,6 +65,48 @@ def cpu_baseline(seconds_target=12.0):
     }
 
 
+def other_configs(torch, tf, device):
+    """Short measurements of the other BASELINE configs and neighbouring lengths on the same GPU, after the headline
+    timing (not part of `value`): Gsamples/s over 10 back-to-back executions each, inputs resident, workspace preset."""
+    out = {}
+
+    def timed(fn, reps=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    for name, n, b in (("n256_x_1048576", 256, 1 << 20), ("n1024_x_262144", 1024, 1 << 18),
+                       ("n8192_x_32768", 8192, 1 << 15), ("n65536_x_4096", 1 << 16, 1 << 12),
+                       ("configs[2]_n2^20_x_1024", 1 << 20, 1024), ("n2^24_x_16", 1 << 24, 16),
+                       ("configs[4b]_single_gpu_n2^26_x_1", 1 << 26, 1)):
+        x = (torch.rand(b * 2 * n, device="cuda") * 2 - 1).to(torch.float16)
+        y = torch.empty_like(x)
+        plan = tf.TfftPlan(n, b, device, preserve_input=True)
+        ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+        if plan.workspace_bytes:
+            plan.set_workspace(ws)
+        ms = timed(lambda: plan.exec(x, x[n:], y, y[n:]))
+        out[name] = {"gsamples_per_s": n * b / ms / 1e6, "ms": ms, "passes": plan.num_launches}
+        del plan, x, y, ws
+        torch.cuda.empty_cache()
+    rows = cols = 4096
+    images = 64
+    x = (torch.rand(images * 2 * rows * cols, device="cuda") * 2 - 1).to(torch.float16)
+    y = torch.empty_like(x)
+    plan2 = tf.TfftPlan2D(rows, cols, images, device)
+    half = images * rows * cols                      # fully planar: all RE images, then all IM images
+    ms = timed(lambda: plan2.exec(x[:half], x[half:], y[:half], y[half:]), reps=5)
+    out["configs[3]_2d_4096x4096_x_64"] = {"gsamples_per_s": half / ms / 1e6, "ms": ms, "passes": plan2.num_launches}
+    return out
+
+
 def shard(rank, world, total):
     """Contiguous slice [lo, hi) of `total` independent transforms owned by `rank`: the whole multi-GPU story of
     the batched path (FFTs are independent, no data-path collective). bench.py itself runs weak
@@ -96,6 +140,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH, help="transforms per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short extra measurements of the other BASELINE configs (reported under 'other_configs')")
     args = ap.parse_args()
 
     import torch
@@ -210,6 +256,10 @@ def main():
             "mfma": {"tflops": mfma_tflops, "peak": MFMA_PEAK_TFLOPS, "frac": mfma_tflops / MFMA_PEAK_TFLOPS,
                      "flop_per_sample": 384},
         }
+        if world == 1 and not args.no_other_configs and batch == BATCH:
+            del x, y
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(torch, tf, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
