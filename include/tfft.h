@@ -139,6 +139,22 @@ int tfft_exec(const tfft_plan* plan, const void* in_re, const void* in_im, void*
 int tfft_exec_inverse(const tfft_plan* plan, const void* in_re, const void* in_im, void* out_re,
                       void* out_im, void* stream);
 
+/* 2D transform of `batch` images [rows][cols] (BASELINE config "2D 4096 x 4096, batch 64"; the reference has no 2D
+ * entry point, this is its 1D path (ComputeFFT.h:162-293) used twice): a row pass over contiguous lines (N = cols,
+ * batch * rows transforms) and a column pass along the strided axis (N = rows, inner = cols). Layout: fully planar,
+ * in_re / in_im / out_re / out_im each point at batch * rows * cols halves, image after image, row-major.
+ * Result = DFT2(x) / (rows * cols). rows, cols: powers of two, cols >= 8.
+ * Scratch: tfft_plan2d_workspace_bytes() of device memory (an intermediate image set plus the column plan's own
+ * scratch); hand it in with tfft_plan2d_set_workspace() or let the first execution hipMalloc it. */
+typedef struct tfft_plan2d tfft_plan2d;
+int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_id, tfft_plan2d** out);
+void tfft_plan2d_destroy(tfft_plan2d* plan);
+int tfft_plan2d_num_launches(const tfft_plan2d* plan);
+size_t tfft_plan2d_workspace_bytes(const tfft_plan2d* plan);
+int tfft_plan2d_set_workspace(tfft_plan2d* plan, void* device_ptr, size_t bytes);
+int tfft_plan2d_exec(const tfft_plan2d* plan, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                     void* stream);
+
 /* out[b][a][c] = in[a][b][c] * w_n_tw^((e0 + b) * (a*C + c)), planar binary16, c contiguous (C % 8 == 0);
  * n_tw == 0: pure re-ordering. The pack / twiddle / unpack step around the single all-to-all of a transform
  * distributed over several GPUs; the reference has no counterpart (no multi-device path,

@@ -17,6 +17,8 @@ SYMBOLS = [
     "tfft_plan_destroy", "tfft_plan_num_launches", "tfft_plan_workspace_bytes", "tfft_plan_set_workspace",
     "tfft_exec", "tfft_plan_kernel_name", "tfft_plan_algorithmic_bytes", "tfft_plan_mfma_flops",
     "tfft_last_error", "tfft_version", "tfft_permute_twiddle", "tfft_exec_inverse", "tfft_deinterleave", "tfft_interleave",
+    "tfft_plan2d_create", "tfft_plan2d_destroy", "tfft_plan2d_num_launches", "tfft_plan2d_workspace_bytes",
+    "tfft_plan2d_set_workspace", "tfft_plan2d_exec",
 ]
 
 
@@ -107,6 +109,18 @@ def load_library():
     L.tfft_exec_inverse.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tfft_permute_twiddle.restype = ci
     L.tfft_permute_twiddle.argtypes = [vp, vp, vp, vp, u64, u64, u64, u64, u64, vp]
+    L.tfft_plan2d_create.restype = ci
+    L.tfft_plan2d_create.argtypes = [u64, u64, u64, ci, ctypes.POINTER(vp)]
+    L.tfft_plan2d_destroy.restype = None
+    L.tfft_plan2d_destroy.argtypes = [vp]
+    L.tfft_plan2d_num_launches.restype = ci
+    L.tfft_plan2d_num_launches.argtypes = [vp]
+    L.tfft_plan2d_workspace_bytes.restype = ctypes.c_size_t
+    L.tfft_plan2d_workspace_bytes.argtypes = [vp]
+    L.tfft_plan2d_set_workspace.restype = ci
+    L.tfft_plan2d_set_workspace.argtypes = [vp, vp, ctypes.c_size_t]
+    L.tfft_plan2d_exec.restype = ci
+    L.tfft_plan2d_exec.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tfft_plan_kernel_name.restype = ctypes.c_char_p
     L.tfft_plan_kernel_name.argtypes = [vp]
     L.tfft_plan_algorithmic_bytes.restype = ctypes.c_double
@@ -233,32 +247,56 @@ def permute_twiddle(in_re, in_im, out_re, out_im, a, b, c, n_tw=0, e0=0, stream=
 
 class TfftPlan2D:
     """2D transform of `batch` images [rows][cols] (fully planar: all RE images, then all IM images), result
-    DFT2(x) / (rows * cols). Composed of two 1D plans of the C ABI, as BASELINE config 4 describes it: a row
-    pass over contiguous lines (N = cols, batch = batch * rows) and a column pass along the strided axis
-    (N = rows, inner = cols). The reference has no 2D transform; this is its 1D path used twice."""
+    DFT2(x) / (rows * cols): tfft_plan2d_* of the C ABI, i.e. BASELINE config 4 as it describes it: a row pass over
+    contiguous lines (N = cols, batch = batch * rows) and a column pass along the strided axis (N = rows,
+    inner = cols). The reference has no 2D transform; this is its 1D path used twice."""
 
     def __init__(self, rows, cols, batch=1, device=0):
+        self._lib = load_library()
         self.rows, self.cols, self.batch, self.device = int(rows), int(cols), int(batch), int(device)
-        self.row_plan = TfftPlan(cols, batch * rows, device, in_batch_stride=cols, out_batch_stride=cols,
-                                 preserve_input=True)
-        self.col_plan = TfftPlan(rows, batch, device, in_batch_stride=rows * cols, out_batch_stride=rows * cols,
-                                 inner=cols)
-        self._tmp = None
+        h = ctypes.c_void_p()
+        _check(self._lib.tfft_plan2d_create(self.rows, self.cols, self.batch, self.device, ctypes.byref(h)))
+        self._h = h
+        self._ws = None
 
     @property
     def num_launches(self):
-        return self.row_plan.num_launches + self.col_plan.num_launches
+        return int(self._lib.tfft_plan2d_num_launches(self._h))
+
+    @property
+    def workspace_bytes(self):
+        return int(self._lib.tfft_plan2d_workspace_bytes(self._h))
+
+    def set_workspace(self, tensor):
+        """Hand the plan a device buffer of at least workspace_bytes (kept referenced by this object)."""
+        _check(self._lib.tfft_plan2d_set_workspace(self._h, tensor.data_ptr(), tensor.numel() * tensor.element_size()))
+        self._ws = tensor
 
     def exec(self, in_re, in_im, out_re, out_im, stream=None):
         import torch
 
         n = self.batch * self.rows * self.cols
-        if self._tmp is None or self._tmp[0].numel() < n or self._tmp[0].device != in_re.device:
-            self._tmp = (torch.empty(n, dtype=torch.float16, device=in_re.device),
-                         torch.empty(n, dtype=torch.float16, device=in_re.device))
-        t_re, t_im = self._tmp
-        self.row_plan.exec(in_re, in_im, t_re, t_im, stream)
-        self.col_plan.exec(t_re, t_im, out_re, out_im, stream)
+        for t in (in_re, in_im, out_re, out_im):
+            if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.numel() >= n):
+                raise TfftError(5, "planes must be contiguous CUDA float16 tensors of batch*rows*cols elements")
+        if self._ws is None:        # torch-owned scratch, so that nothing is hipMalloc'ed behind the caching allocator
+            self.set_workspace(torch.empty(max(1, self.workspace_bytes // 2), dtype=torch.float16, device=in_re.device))
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _check(self._lib.tfft_plan2d_exec(self._h, in_re.data_ptr(), in_im.data_ptr(), out_re.data_ptr(),
+                                              out_im.data_ptr(), stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tfft_plan2d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 def deinterleave(x_half2, out_re, out_im, stream=None):

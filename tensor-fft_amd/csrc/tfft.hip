@@ -696,6 +696,123 @@ int tfft_exec(const tfft_plan* p, const void* in_re, const void* in_im, void* ou
   return launch_chain(p, in_re, in_im, out_re, out_im, static_cast<hipStream_t>(stream));
 }
 
+// ---------------------------------------------------------------------------
+// 2D = row pass + column pass (see include/tfft.h)
+// ---------------------------------------------------------------------------
+struct tfft_plan2d {
+  tfft_plan* row = nullptr;
+  tfft_plan* col = nullptr;
+  uint64_t rows = 0, cols = 0, batch = 0;
+  int device = 0;
+  mutable std::mutex ws_mutex;
+  mutable void* ws = nullptr;
+  mutable size_t ws_bytes = 0;
+  mutable bool ws_owned = false;
+};
+
+int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_id, tfft_plan2d** out) {
+  g_err.clear();
+  if (!out) return fail(TFFT_ERR_ARG, "null plan pointer");
+  *out = nullptr;
+  if (!is_pow2(rows) || !is_pow2(cols) || cols < 8 || rows < 2) return fail(TFFT_ERR_ARG, "rows and cols must be powers of two (cols >= 8)");
+  if (batch == 0) return fail(TFFT_ERR_ARG, "batch must be positive");
+  tfft_plan2d* p = new tfft_plan2d;
+  p->rows = rows;
+  p->cols = cols;
+  p->batch = batch;
+  p->device = device_id;
+  tfft_plan_opts ro{};
+  ro.in_batch_stride = cols;        // fully planar lines
+  ro.out_batch_stride = cols;
+  ro.preserve_input = 1;
+  int rc = tfft_plan_create(cols, batch * rows, device_id, &ro, &p->row);
+  if (rc == TFFT_OK) {
+    tfft_plan_opts co{};
+    co.in_batch_stride = rows * cols;
+    co.out_batch_stride = rows * cols;
+    co.inner = cols;
+    rc = tfft_plan_create(rows, batch, device_id, &co, &p->col);
+  }
+  if (rc != TFFT_OK) {
+    const std::string keep = g_err;
+    tfft_plan2d_destroy(p);
+    g_err = keep;
+    return rc;
+  }
+  *out = p;
+  return TFFT_OK;
+}
+
+void tfft_plan2d_destroy(tfft_plan2d* p) {
+  if (!p) return;
+  tfft_plan_destroy(p->row);
+  tfft_plan_destroy(p->col);
+  if (p->ws && p->ws_owned) (void)hipFree(p->ws);
+  delete p;
+}
+
+int tfft_plan2d_num_launches(const tfft_plan2d* p) {
+  return p ? tfft_plan_num_launches(p->row) + tfft_plan_num_launches(p->col) : 0;
+}
+
+namespace {
+inline size_t plan2d_tmp_bytes(const tfft_plan2d* p) { return static_cast<size_t>(p->batch) * p->rows * p->cols * 4; }
+inline size_t plan2d_part(size_t bytes) { return (bytes + 255) & ~static_cast<size_t>(255); }
+}  // namespace
+
+size_t tfft_plan2d_workspace_bytes(const tfft_plan2d* p) {
+  if (!p) return 0;
+  return plan2d_part(plan2d_tmp_bytes(p)) + plan2d_part(tfft_plan_workspace_bytes(p->row)) +
+         tfft_plan_workspace_bytes(p->col);
+}
+
+int tfft_plan2d_set_workspace(tfft_plan2d* p, void* device_ptr, size_t bytes) {
+  g_err.clear();
+  if (!p) return fail(TFFT_ERR_ARG, "null plan");
+  std::lock_guard<std::mutex> lock(p->ws_mutex);
+  if (p->ws && p->ws_owned) (void)hipFree(p->ws);
+  p->ws = device_ptr;
+  p->ws_bytes = device_ptr ? bytes : 0;
+  p->ws_owned = false;
+  return TFFT_OK;
+}
+
+int tfft_plan2d_exec(const tfft_plan2d* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                     void* stream) {
+  g_err.clear();
+  if (!p) return fail(TFFT_ERR_ARG, "null plan");
+  const size_t need = tfft_plan2d_workspace_bytes(p);
+  {
+    std::lock_guard<std::mutex> lock(p->ws_mutex);
+    if (!p->ws || p->ws_bytes < need) {
+      if (p->ws && !p->ws_owned) return fail(TFFT_ERR_WORKSPACE, "workspace handed to tfft_plan2d_set_workspace is too small");
+      int prev = 0;
+      TFFT_HIP(hipGetDevice(&prev));
+      TFFT_HIP(hipSetDevice(p->device));
+      if (p->ws) (void)hipFree(p->ws);
+      p->ws = nullptr;
+      const hipError_t e = hipMalloc(&p->ws, need);
+      (void)hipSetDevice(prev);
+      if (e != hipSuccess) return hip_fail(e, "hipMalloc(2D workspace)");
+      p->ws_bytes = need;
+      p->ws_owned = true;
+    }
+    uint8_t* base = static_cast<uint8_t*>(p->ws);
+    const size_t tmp = plan2d_part(plan2d_tmp_bytes(p)), row_ws = plan2d_part(tfft_plan_workspace_bytes(p->row));
+    int rc = tfft_plan_set_workspace(p->row, row_ws ? base + tmp : nullptr, row_ws);
+    if (rc == TFFT_OK) {
+      const size_t col_ws = tfft_plan_workspace_bytes(p->col);
+      rc = tfft_plan_set_workspace(p->col, col_ws ? base + tmp + row_ws : nullptr, col_ws);
+    }
+    if (rc != TFFT_OK) return rc;
+  }
+  _Float16* t_re = static_cast<_Float16*>(p->ws);
+  _Float16* t_im = t_re + static_cast<size_t>(p->batch) * p->rows * p->cols;
+  int rc = tfft_exec(p->row, in_re, in_im, t_re, t_im, stream);
+  if (rc != TFFT_OK) return rc;
+  return tfft_exec(p->col, t_re, t_im, out_re, out_im, stream);
+}
+
 int tfft_permute_twiddle(const void* in_re, const void* in_im, void* out_re, void* out_im, uint64_t a, uint64_t b,
                          uint64_t c, uint64_t n_tw, uint64_t e0, void* stream) {
   g_err.clear();

@@ -11,7 +11,7 @@ b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 re = ((torch.rand(b * n * n, device="cuda") * 2 - 1)).half(); im = ((torch.rand(b * n * n, device="cuda") * 2 - 1)).half()
 o_re, o_im = torch.empty_like(re), torch.empty_like(im)
 plan = tf.TfftPlan2D(n, n, b, 0)
-ws = torch.empty(plan.col_plan.workspace_bytes // 2, dtype=torch.float16, device="cuda"); plan.col_plan.set_workspace(ws)
+ws = torch.empty(plan.workspace_bytes // 2, dtype=torch.float16, device="cuda"); plan.set_workspace(ws)
 for _ in range(2): plan.exec(re, im, o_re, o_im)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
