@@ -9,7 +9,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n,batch,inner", [(4096, 2048, 1), (1 << 13, 512, 1), (1 << 16, 128, 1), (1 << 20, 8, 1),
-                                            (256, 16, 1024), (4096, 2, 2048)])
+                                            (256, 16, 1024), (4096, 2, 2048),
+                                            (256, 40000, 1), (512, 9000, 1), (1024, 7000, 1), (2048, 3000, 1),   # single-pass kernels
+                                            (1 << 13, 515, 1), (1 << 14, 255, 1),    # narrow column pass + ragged remainder, radix-32/64 tails
+                                            (1 << 15, 64, 1), (1 << 21, 4, 1), (1 << 17, 32, 1)])
 def test_repeated_runs_are_bit_identical(n, batch, inner):
     import torch
     import __graft_entry__ as g
