@@ -280,6 +280,42 @@ __global__ __launch_bounds__(kBlock) void pass_kernel(PassArgs a) {
   }
 }
 
+// Two adjacent butterflies per thread (j and j + 1), for passes whose input twiddles were already applied by the
+// preceding column pass (skip_tw) and whose sub-transform length is even: every global access is 4 bytes per lane
+// (256 contiguous bytes per wave instruction) instead of 2.
+template <int R>
+__global__ __launch_bounds__(kBlock) void pass_pair_kernel(PassArgs a) {
+  const uint64_t gid = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x;
+  const uint64_t m = a.m_f;
+  const uint64_t fft = gid >> (a.m_shift - 1);
+  if (fft >= a.batch) return;
+  const uint64_t j = (gid & ((m >> 1) - 1)) << 1;
+  const uint64_t k = j & (a.ns - 1);
+  const _Float16* xr = a.in_re + fft * a.in_stride + j;
+  const _Float16* xi = a.in_im + fft * a.in_stride + j;
+  typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
+  cf v0[R], v1[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const hv2 pr = *reinterpret_cast<const hv2*>(xr + i * m);
+    const hv2 pi = *reinterpret_cast<const hv2*>(xi + i * m);
+    v0[i] = cf{static_cast<float>(pr[0]), static_cast<float>(pi[0])};
+    v1[i] = cf{static_cast<float>(pr[1]), static_cast<float>(pi[1])};
+  }
+  dft<R>(v0);
+  dft<R>(v1);
+  const float sc = 1.0f / R;
+  _Float16* yr = a.out_re + fft * a.out_stride + (j - k) * R + k;
+  _Float16* yi = a.out_im + fft * a.out_stride + (j - k) * R + k;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const hv2 pr = {static_cast<_Float16>(v0[i].re * sc), static_cast<_Float16>(v1[i].re * sc)};
+    const hv2 pi = {static_cast<_Float16>(v0[i].im * sc), static_cast<_Float16>(v1[i].im * sc)};
+    *reinterpret_cast<hv2*>(yr + i * a.ns) = pr;
+    *reinterpret_cast<hv2*>(yi + i * a.ns) = pi;
+  }
+}
+
 // plain planar copy (in-place requests whose pass chain cannot start from `in`)
 __global__ __launch_bounds__(kBlock) void copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                        uint64_t n32) {
