@@ -612,4 +612,227 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Radix-512 column pass (columns-in-registers form, Ns >= 64): rows i = 2 m + q. The two decimated sequences
+// q = 0, 1 are two radix-256 problems, handled by waves 0-3 and 4-7 of the workgroup exactly as the 4-wave
+// cooperative kernel above handles one (64 columns, 128-byte row segments, one 32-KiB half-image per plane and
+// sequence). The q = 1 half multiplies its stage-2 output by w_512^k (k = ka + 16 kb: a per-lane base times a
+// 16-step recurrence over ka, as for the inter-pass twiddles). Both halves leave A_q[k][column] in LDS; the read-out
+// forms X[k] = A_0 + A_1, X[k + 256] = A_0 - A_1 in fp32, applies the next pass's input twiddles there (they depend
+// on the full output index), rounds once and stores two 128-byte row segments per lane group.
+// One pass over HBM for a radix the 160-KiB LDS could not hold as one 512-row image of 256-byte segments:
+// 2^17 = 256 x 512 and 2^26 = 256 x 512 x 512 take one pass fewer.
+// ---------------------------------------------------------------------------
+constexpr int kWg512LdsBytes = kLdsTable + 4 * WgGeom<4>::kPlane;   // 144 KiB
+
+__device__ __forceinline__ cpx lookup_n(const Args& a, uint64_t e_n) {   // w_N^(e_n), e_n already reduced mod N
+  const float2 lo = a.tw_lo[e_n & 8191];
+  cpx w = {lo.x, lo.y};
+  if (a.n_mask >= 8192) {
+    const float2 hi = a.tw_hi[e_n >> 13];
+    w = cmul(w, cpx{hi.x, hi.y});
+  }
+  return w;
+}
+
+template <bool TW>
+__global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
+  using G = WgGeom<4>;
+  constexpr int kHalf = G::kPlane;        // one sequence, one plane: 256 rows x 128 B
+  constexpr int kPlaneAll = 2 * kHalf;    // RE -> IM distance
+  constexpr int kRps = G::kRps, kCpr = G::kCpr;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int seq = wave >> 2, w4 = wave & 3;   // decimated sequence q, wave within its half
+  for (int i = tid; i < kLdsTable / 16; i += kThreads)
+    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(a.tables + kOffG)[i];
+  const h8 f_re = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32);
+  const h8 f_im = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32 + 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  uint8_t* const img = lds + kLdsTable;
+  uint8_t* const img_q = img + seq * kHalf;
+  const uint32_t img_q_off = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)img_q)));
+  const uint8_t* const g_tab = lds + lane * 16;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, x = lane & 15;
+  const int ihi = 4 * g + q;
+  const uint8_t* tr_base[kRps];
+#pragma unroll
+  for (int h = 0; h < kRps; ++h)
+    tr_base[h] = img_q + (16 / kRps) * ihi * 256 + 16 * ((h * kCpr + 2 * w4 + (p >> 1)) ^ (2 * (ihi & 7))) + 8 * (p & 1);
+  const uint32_t pshift = static_cast<uint32_t>(__builtin_ctzll(a.pitch));
+  const uint32_t total = static_cast<uint32_t>(((a.tasks / a.groups) << pshift) / G::kCols);
+  const uint64_t n512 = (a.n_mask + 1) >> 9;   // w_512 = w_N^(N / 512)
+  // combine twiddle of the odd sequence: w_512^(ka + 16 kb), kb = x
+  cpx c_base = {1.f, 0.f}, c_step = {1.f, 0.f};
+  if (seq == 1) {
+    c_base = lookup_n(a, (16 * x) * n512);
+    c_step = lookup_n(a, n512);
+  }
+
+  for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;
+    const uint64_t bidx = gc0 >> pshift;                     // pitch >= 64: one batch entry per block
+    const uint64_t mb = gc0 & (a.pitch - 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t sr = 32 * w4 + 4 * i + (lane >> 4);
+      const uint32_t v = (lane & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
+      const uint32_t r = sr * kRps + v / kCpr;               // row of the sequence's 256-row image
+      const uint32_t chunk = v % kCpr;
+      const uint64_t off = ((2 * r + seq) * a.pitch + mb + 8 * chunk) * 2;
+      const uint8_t* gr = reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off;
+      const uint8_t* gi = reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off;
+      const uint32_t d0 = img_q_off + 8192 * w4 + 1024 * i, d1 = d0 + kPlaneAll;
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off nt\n\t"
+          "s_mov_b32 m0, %4\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %2, off nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+          : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // A: both half-images are in LDS
+
+    // ---- stage 1
+    uint32_t pr[8][4], pi[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f4 dre[2], dim[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i_lo = 2 * t + e;
+        const uint8_t* ad = tr_base[i_lo % kRps] + (i_lo / kRps) * 256;
+        const s4 xr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad));
+        const s4 xi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad + kPlaneAll));
+        const u4 raw = {__builtin_bit_cast(u2, xr).x, __builtin_bit_cast(u2, xr).y,
+                        __builtin_bit_cast(u2, xi).x, __builtin_bit_cast(u2, xi).y};
+        const h8 xv = __builtin_bit_cast(h8, raw);
+        dre[e] = mfma(f_re, xv);
+        dim[e] = mfma(f_im, xv);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[t][r] = pk(dre[0][r], dre[1][r]);
+        pi[t][r] = pk(dim[0][r], dim[1][r]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // B: every wave has read its slab; the images may be overwritten
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        transpose4(pr[0 + pp][r], pr[2 + pp][r], pr[4 + pp][r], pr[6 + pp][r]);
+        transpose4(pi[0 + pp][r], pi[2 + pp][r], pi[4 + pp][r], pi[6 + pp][r]);
+      }
+
+    // ---- stage 2 (data as the A operand: lane = kb, registers = 4 adjacent columns), combine twiddle, A_q -> LDS
+    cpx pw = {1.f, 0.f};
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) {
+      const int aa = ka >> 2, r0 = ka & 3;
+      const u4 draw = {pr[2 * aa][r0], pr[2 * aa + 1][r0], pi[2 * aa][r0], pi[2 * aa + 1][r0]};
+      const h8 dop = __builtin_bit_cast(h8, draw);
+      const u4 graw = *reinterpret_cast<const u4*>(g_tab + ka * 1024);
+      f4 e_re = mfma(dop, __builtin_bit_cast(h8, graw));
+      f4 e_im = mfma(dop, im_form(graw));
+      if (seq == 1) {
+        const cpx wt = cmul(c_base, pw);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float vr = __builtin_fmaf(e_re[r], wt.re, -(e_im[r] * wt.im));
+          const float vi = __builtin_fmaf(e_re[r], wt.im, e_im[r] * wt.re);
+          e_re[r] = vr;
+          e_im[r] = vi;
+        }
+        pw = cmul(pw, c_step);
+      }
+      const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
+      const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
+      uint8_t* dst = img_q + ((ka / kRps) + (16 / kRps) * x) * 256 +
+                     16 * (((ka % kRps) * kCpr + 2 * w4 + (g >> 1)) ^ (2 * (x & 7))) + 8 * (g & 1);
+      *reinterpret_cast<u2*>(dst) = vr;
+      *reinterpret_cast<u2*>(dst + kPlaneAll) = vi;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // C: A_0 and A_1 are complete
+
+    // ---- radix-2 combine at read-out: this thread takes 16-byte chunks (8 columns) of rows k and k + 256
+    uint16_t* const o_re = a.out_re + bidx * a.out_stride;
+    uint16_t* const o_im = a.out_im + bidx * a.out_stride;
+    const uint64_t restb = mb >> a.ns_f_shift;                 // shared by the block's 64 columns (ns_f % 64 == 0)
+    const uint64_t obase = ((restb << 9) << a.ns_f_shift) + (mb - (restb << a.ns_f_shift));
+    cpx w_av = {1.f, 0.f}, w_half = {1.f, 0.f};
+    uint64_t av = 0;
+    if (TW) {
+      av = restb >> a.a_shift;
+      w_av = lookup<true>(a, av & a.t_mask);                                               // w_T^av (per unit of kprev)
+      w_half = lookup<true>(a, (av * ((a.ns * 256) & a.t_mask)) & a.t_mask);               // w_T^(av ns 256)
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const uint32_t L = it * kThreads + tid;                  // 16-byte slot of the half-image
+      const uint32_t sr = L >> 4;
+      const uint32_t v = (L & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
+      const uint32_t k = sr * kRps + v / kCpr;
+      const uint32_t chunk = v % kCpr;
+      const u4 a_re = *reinterpret_cast<const u4*>(img + 16 * L);
+      const u4 b_re = *reinterpret_cast<const u4*>(img + kHalf + 16 * L);
+      const u4 a_im = *reinterpret_cast<const u4*>(img + kPlaneAll + 16 * L);
+      const u4 b_im = *reinterpret_cast<const u4*>(img + kPlaneAll + kHalf + 16 * L);
+      const h8 ar = __builtin_bit_cast(h8, a_re), br = __builtin_bit_cast(h8, b_re);
+      const h8 ai = __builtin_bit_cast(h8, a_im), bi = __builtin_bit_cast(h8, b_im);
+      float x0r[8], x0i[8], x1r[8], x1i[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float Ar = static_cast<float>(ar[e]), Br = static_cast<float>(br[e]);
+        const float Ai = static_cast<float>(ai[e]), Bi = static_cast<float>(bi[e]);
+        x0r[e] = 0.5f * (Ar + Br);
+        x0i[e] = 0.5f * (Ai + Bi);
+        x1r[e] = 0.5f * (Ar - Br);
+        x1i[e] = 0.5f * (Ai - Bi);
+      }
+      if (TW) {
+        // E = av (kprev + ns k') mod T; kprev of column e of this chunk = (kprev_f0 + e) >> inner_shift
+        const uint64_t kprev_f0 = (mb + 8 * chunk) - (restb << a.ns_f_shift);
+        const cpx row0 = lookup<true>(a, (av * ((a.ns * k) & a.t_mask)) & a.t_mask);
+        const cpx row1 = cmul(row0, w_half);
+        cpx col = lookup<true>(a, (av * ((kprev_f0 >> a.inner_shift) & a.t_mask)) & a.t_mask);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const cpx t0 = cmul(col, row0), t1 = cmul(col, row1);
+          const float r0 = x0r[e] * t0.re - x0i[e] * t0.im, i0 = x0r[e] * t0.im + x0i[e] * t0.re;
+          const float r1 = x1r[e] * t1.re - x1i[e] * t1.im, i1 = x1r[e] * t1.im + x1i[e] * t1.re;
+          x0r[e] = r0; x0i[e] = i0; x1r[e] = r1; x1i[e] = i1;
+          if (a.inner_shift == 0) col = cmul(col, w_av);       // next column: kprev + 1 (inner > 1: 8 columns share kprev)
+        }
+      }
+      const u4 s0r = {pk(x0r[0], x0r[1]), pk(x0r[2], x0r[3]), pk(x0r[4], x0r[5]), pk(x0r[6], x0r[7])};
+      const u4 s0i = {pk(x0i[0], x0i[1]), pk(x0i[2], x0i[3]), pk(x0i[4], x0i[5]), pk(x0i[6], x0i[7])};
+      const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
+      const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
+      const uint64_t o0 = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
+      const uint64_t o1 = o0 + (static_cast<uint64_t>(256) << a.ns_f_shift);
+      __builtin_nontemporal_store(s0r, reinterpret_cast<u4*>(o_re + o0));
+      __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(o_im + o0));
+      __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(o_re + o1));
+      __builtin_nontemporal_store(s1i, reinterpret_cast<u4*>(o_im + o1));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // D: read out; the next block's copy-in may overwrite the images
+  }
+}
+
 }  // namespace colfft

@@ -51,7 +51,7 @@ enum class PassKind { K4096, K256, K256R, Col256, Stockham };
 
 struct Pass {
   PassKind kind;
-  int radix;          // 4096, 256, or 2/4/8/16
+  int radix;          // K4096: 4096; K256: 256; K256R: N / 256; Col256: 256 or 512; Stockham: 2 .. 64
   uint64_t ns;        // unflattened product of the radices before this pass
   bool tw_next;       // Col256: apply the next pass's input twiddles to the output
   bool skip_tw;       // Stockham: input twiddles were applied by the previous pass
@@ -267,7 +267,8 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   a.out_im = reinterpret_cast<uint16_t*>(dst.im);
   a.in_stride = src.stride;
   a.out_stride = dst.stride;
-  a.pitch = (p->n / 256) * p->inner;
+  const uint64_t radix = static_cast<uint64_t>(ps.radix);   // 256, or 512 (columns-in-registers form only)
+  a.pitch = (p->n / radix) * p->inner;
   a.ns_f = ps.ns * p->inner;
   a.ns_f_shift = static_cast<uint32_t>(ilog2(a.ns_f));
   a.groups = static_cast<uint32_t>(a.pitch / 16);
@@ -286,11 +287,31 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   if (ps.tw_next) {
     // next pass: radix R', Ns'' = ns * 256; it wants w_T^(i' k''), T = Ns'' R', on element
     // o = rest (ns_f 256) + k ns_f + kprev_f:  k'' = k ns + kprev,  i' = o / (n_f / R') = rest >> a_shift
-    const uint64_t t = ps.ns * 256 * static_cast<uint64_t>(ps.next_radix);
+    const uint64_t t = ps.ns * radix * static_cast<uint64_t>(ps.next_radix);
     a.t_mask = t - 1;
     a.n_over_t = p->n / t;
     a.inv_t = 1.0 / static_cast<double>(t);
-    a.a_shift = static_cast<uint32_t>(ilog2(p->n / (static_cast<uint64_t>(ps.next_radix) * ps.ns * 256)));
+    a.a_shift = static_cast<uint32_t>(ilog2(p->n / (static_cast<uint64_t>(ps.next_radix) * ps.ns * radix)));
+  }
+  if (radix == 512) {
+    // plan creation only emits this pass where the geometry fits (pitch and ns_f multiples of 64, not the first pass)
+    static std::once_flag once[16];
+    hipError_t attr = hipSuccess;
+    std::call_once(once[p->device & 15], [&] {
+      attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWg512LdsBytes);
+      if (attr == hipSuccess)
+        attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWg512LdsBytes);
+    });
+    if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+    const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
+    if (ps.tw_next)
+      hipLaunchKernelGGL(colfft::colfft512_wg_kernel<true>, dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+    else
+      hipLaunchKernelGGL(colfft::colfft512_wg_kernel<false>, dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+    return TFFT_OK;
   }
   // default: stores straight from registers (8- / 16-byte pieces); variant bit 4096: stage the output through
   // LDS (16-byte coalesced stores). Measured in one process on MI355X: direct wins at 2^16 and 2^20, staging at 2^13.
@@ -601,6 +622,19 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     if (col_ok) n256 = lg / 8;
     int rem = lg - 8 * n256;
     std::vector<int> radices(n256, 256);
+    // Radix-512 column passes (never the first pass) where they save a whole pass: 2^17 = 256 x 512,
+    // 2^23 = 256 x 512 x 64, 2^25 = 256 x 256 x 512, 2^26 = 256 x 512 x 512. variant bit 8388608 turns them off.
+    const bool use512 = col_ok && inner == 1 && !(opts && (opts->variant & 8388608));
+    if (use512 && n256 >= 2 && rem == 1) {
+      radices[n256 - 1] = 512;
+      rem = 0;
+    } else if (use512 && n256 >= 3 && rem == 2) {
+      radices[n256 - 1] = radices[n256 - 2] = 512;
+      rem = 0;
+    } else if (use512 && n256 >= 2 && rem == 7) {
+      radices[n256 - 1] = 512;
+      rem = 6;
+    }
     for (; rem >= 4; rem -= 4) radices.push_back(16);
     if (rem) radices.push_back(1 << rem);
     // a radix-16 pass followed by a radix-2 / radix-4 pass behind a column pass fuses into one radix-32 / radix-64
@@ -617,12 +651,12 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     for (size_t i = 0; i < radices.size(); ++i) {
       const int R = radices[i];
       const bool last = (i + 1 == radices.size());
-      if (R == 256) {
+      if (R == 256 || R == 512) {
         const bool no_tw = opts && (opts->variant & 128);   // debugging aid: WRONG results, timing/determinism only
-        p->passes.push_back(Pass{PassKind::Col256, 256, ns, !last && !no_tw, false, last ? 0 : radices[i + 1]});
+        p->passes.push_back(Pass{PassKind::Col256, R, ns, !last && !no_tw, false, last ? 0 : radices[i + 1]});
         need_tables = true;
       } else {
-        const bool prev_col = i > 0 && radices[i - 1] == 256;
+        const bool prev_col = i > 0 && radices[i - 1] >= 256;
         p->passes.push_back(Pass{PassKind::Stockham, R, ns, false, prev_col, 0});
       }
       ns *= static_cast<uint64_t>(R);

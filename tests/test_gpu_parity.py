@@ -331,6 +331,28 @@ def test_narrow_pitch_cooperative_column_pass(tf, torch, orc, n, batch):
     _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_256)
 
 
+@pytest.mark.parametrize("lg,batch", [(17, 1), (17, 5), (23, 1), (25, 1)])
+def test_radix512_column_pass(tf, torch, orc, lg, batch):
+    """2^17 = 256 x 512, 2^23 = 256 x 512 x 64, 2^25 = 256 x 256 x 512: the radix-512 column pass (two decimated radix-256
+    halves + radix-2 combine at read-out, with and without the next pass's twiddles) against the oracle, and
+    against the chain without it (variant bit 8388608), which must agree to fp16 rounding."""
+    n = 1 << lg
+    rng = np.random.default_rng(lg + batch)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    plan = tf.TfftPlan(n, batch, 0)
+    other = tf.TfftPlan(n, batch, 0, variant=8388608)
+    assert plan.num_launches == other.num_launches - 1
+    gr, gi = _run(tf, torch, re, im)
+    exact = _c(*orc.dft64(re, im))
+    got = _c(gr, gi)
+    assert np.isfinite(got).all()
+    assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL
+    pr, pi = _run(tf, torch, re, im, variant=8388608)
+    ref = _c(pr, pi)
+    assert np.abs(got - exact).max() <= 1.5 * np.abs(ref - exact).max() + 2.0 ** -11 * np.abs(exact).max()
+
+
 @pytest.mark.parametrize("lg", [13, 16, 17])
 def test_plain_autosort_chain_still_correct(tf, torch, orc, lg):
     """variant bit 32 forces the radix-2/4/8/16 autosort chain (no radix-256 column kernel)."""
@@ -602,7 +624,7 @@ def test_one_plan_from_several_host_threads(tf, torch):
         assert bool((g_ == w_).all())
 
 
-@pytest.mark.parametrize("lg", [8, 9, 11, 12, 13, 15, 16, 18, 20, 21])
+@pytest.mark.parametrize("lg", [8, 9, 11, 12, 13, 15, 16, 17, 18, 20, 21, 23, 25, 26])
 def test_against_vendor_fft_on_device(tf, torch, lg):
     """Independent cross-check that needs no CPU oracle: hipFFT (through torch.fft, complex64) on the same fp16 input,
     the role cuFFT plays in the reference's tests (CuFFTTest.h:193-261). Large N run here in seconds."""
