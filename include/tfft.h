@@ -105,7 +105,8 @@ typedef struct tfft_plan_opts {
                            the output through LDS (full-row stores), 8 = non-temporal loads/stores, 16 = none of
                            these (default = 2|8); 4 and 64 are timing-only (WRONG results).
                            Any N: 32 = plain autosort chain (no column kernel); 2097152 = do not fuse the
-                           radix-16 + radix-2/4 tail into one radix-32/64 pass.
+                           radix-16 + radix-2/4 tail into one radix-32/64 pass; 8388608 = no radix-512 column
+                           passes; 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
                            Column passes: 131072 = per-wave kernel, 524288 = 4-wave cooperative workgroups,
                            262144 = no non-temporal accesses, 1048576 = 16-byte stores straight from registers,
                            4096 / 8192 = per-wave kernel with LDS-staged stores / hardware sin-cos twiddles.

@@ -635,7 +635,14 @@ __device__ __forceinline__ cpx lookup_n(const Args& a, uint64_t e_n) {   // w_N^
   return w;
 }
 
-template <bool TW>
+// Next-pass twiddles of the radix-512 read-out: v_sin / v_cos (absolute error ~1e-6, three orders below binary16's
+// resolution) instead of the two-level fp32 tables: measured +3-6 % on 2^15 / 2^18 (six dependent loads per chunk less).
+#ifndef TFFT_LUT512
+#define TFFT_LUT512 0
+#endif
+constexpr bool kLut512 = TFFT_LUT512;
+
+template <int MODE, bool TW>
 __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
   using G = WgGeom<4>;
   constexpr int kHalf = G::kPlane;        // one sequence, one plane: 256 rows x 128 B
@@ -667,10 +674,13 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
   const uint32_t pshift = static_cast<uint32_t>(__builtin_ctzll(a.pitch));
   const uint32_t total = static_cast<uint32_t>(((a.tasks / a.groups) << pshift) / G::kCols);
   const uint64_t n512 = (a.n_mask + 1) >> 9;   // w_512 = w_N^(N / 512)
-  // combine twiddle of the odd sequence: w_512^(ka + 16 kb), kb = x
-  cpx c_base = {1.f, 0.f}, c_step = {1.f, 0.f};
+  // combine twiddle of the odd sequence: w_512^(ka + 16 kb); kb = x (columns in registers) or 4 g + r (columns on lanes)
+  cpx c_base[4], c_step = {1.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c_base[r] = cpx{1.f, 0.f};
   if (seq == 1) {
-    c_base = lookup_n(a, (16 * x) * n512);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c_base[r] = lookup_n(a, (16 * ((MODE == kColsOnLanes) ? (4 * g + r) : x)) * n512);
     c_step = lookup_n(a, n512);
   }
 
@@ -738,20 +748,30 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
         transpose4(pi[0 + pp][r], pi[2 + pp][r], pi[4 + pp][r], pi[6 + pp][r]);
       }
 
-    // ---- stage 2 (data as the A operand: lane = kb, registers = 4 adjacent columns), combine twiddle, A_q -> LDS
+    // ---- stage 2, combine twiddle of the odd sequence, A_q -> LDS
+    //   columns in registers: data as the A operand, lane = kb, registers = 4 adjacent columns; image rows = k
+    //   columns on lanes:     data as the B operand, lane = column, registers = kb; image rows = columns (512 B of k)
     cpx pw = {1.f, 0.f};
+    float hold_re[4], hold_im[4];
+    uint32_t acc_re[4][4], acc_im[4][4];
 #pragma unroll
     for (int ka = 0; ka < 16; ++ka) {
       const int aa = ka >> 2, r0 = ka & 3;
       const u4 draw = {pr[2 * aa][r0], pr[2 * aa + 1][r0], pi[2 * aa][r0], pi[2 * aa + 1][r0]};
       const h8 dop = __builtin_bit_cast(h8, draw);
       const u4 graw = *reinterpret_cast<const u4*>(g_tab + ka * 1024);
-      f4 e_re = mfma(dop, __builtin_bit_cast(h8, graw));
-      f4 e_im = mfma(dop, im_form(graw));
+      f4 e_re, e_im;
+      if (MODE == kColsOnLanes) {
+        e_re = mfma(__builtin_bit_cast(h8, graw), dop);
+        e_im = mfma(im_form(graw), dop);
+      } else {
+        e_re = mfma(dop, __builtin_bit_cast(h8, graw));
+        e_im = mfma(dop, im_form(graw));
+      }
       if (seq == 1) {
-        const cpx wt = cmul(c_base, pw);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          const cpx wt = cmul(c_base[r], pw);
           const float vr = __builtin_fmaf(e_re[r], wt.re, -(e_im[r] * wt.im));
           const float vi = __builtin_fmaf(e_re[r], wt.im, e_im[r] * wt.re);
           e_re[r] = vr;
@@ -759,15 +779,92 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
         }
         pw = cmul(pw, c_step);
       }
-      const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
-      const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
-      uint8_t* dst = img_q + ((ka / kRps) + (16 / kRps) * x) * 256 +
-                     16 * (((ka % kRps) * kCpr + 2 * w4 + (g >> 1)) ^ (2 * (x & 7))) + 8 * (g & 1);
-      *reinterpret_cast<u2*>(dst) = vr;
-      *reinterpret_cast<u2*>(dst + kPlaneAll) = vi;
+      if (MODE == kColsInRegs) {
+        const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
+        const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
+        uint8_t* dst = img_q + ((ka / kRps) + (16 / kRps) * x) * 256 +
+                       16 * (((ka % kRps) * kCpr + 2 * w4 + (g >> 1)) ^ (2 * (x & 7))) + 8 * (g & 1);
+        *reinterpret_cast<u2*>(dst) = vr;
+        *reinterpret_cast<u2*>(dst + kPlaneAll) = vi;
+      } else if ((ka & 1) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hold_re[r] = e_re[r];
+          hold_im[r] = e_im[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc_re[r][(ka >> 1) & 3] = pk(hold_re[r], e_re[r]);
+          acc_im[r][(ka >> 1) & 3] = pk(hold_im[r], e_im[r]);
+        }
+        if ((ka & 7) == 7) {
+          const int half = ka >> 3;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // image row 16 w4 + x (512 B: this column's A_q[k]), 16-byte chunk c = 2 (4g + r) + half at slot c ^ x
+            uint8_t* dst = img_q + 8192 * w4 + 512 * x + 16 * ((2 * (4 * g + r) + half) ^ x);
+            *reinterpret_cast<u4*>(dst) = u4{acc_re[r][0], acc_re[r][1], acc_re[r][2], acc_re[r][3]};
+            *reinterpret_cast<u4*>(dst + kPlaneAll) = u4{acc_im[r][0], acc_im[r][1], acc_im[r][2], acc_im[r][3]};
+          }
+        }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // C: A_0 and A_1 are complete
+
+    if (MODE == kColsOnLanes) {
+      // ---- radix-2 combine at read-out: 16-byte chunks = 8 consecutive k of one column; a column's 512 outputs are
+      // 1 KiB contiguous. The next pass's twiddle is w_T^(av k') with av from the column (Ns = 1: kprev = 0).
+      uint16_t* const c_re = a.out_re + bidx * a.out_stride;
+      uint16_t* const c_im = a.out_im + bidx * a.out_stride;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const uint32_t L = it * kThreads + tid;
+        const uint32_t f = L >> 5;                               // column within the block's 64
+        const uint32_t k0 = 8 * ((L & 31) ^ (f & 15));
+        const h8 ar = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + 16 * L));
+        const h8 br = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + kHalf + 16 * L));
+        const h8 ai = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + kPlaneAll + 16 * L));
+        const h8 bi = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + kPlaneAll + kHalf + 16 * L));
+        float x0r[8], x0i[8], x1r[8], x1i[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float Ar = static_cast<float>(ar[e]), Br = static_cast<float>(br[e]);
+          const float Ai = static_cast<float>(ai[e]), Bi = static_cast<float>(bi[e]);
+          x0r[e] = 0.5f * (Ar + Br);
+          x0i[e] = 0.5f * (Ai + Bi);
+          x1r[e] = 0.5f * (Ar - Br);
+          x1i[e] = 0.5f * (Ai - Bi);
+        }
+        if (TW) {
+          const uint64_t av = (mb + f) >> a.a_shift;
+          const cpx w1 = lookup<kLut512>(a, av & a.t_mask);
+          cpx t0 = lookup<kLut512>(a, (av * k0) & a.t_mask);
+          cpx t1 = cmul(t0, lookup<kLut512>(a, (av * 256) & a.t_mask));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float r0 = x0r[e] * t0.re - x0i[e] * t0.im, i0 = x0r[e] * t0.im + x0i[e] * t0.re;
+            const float r1 = x1r[e] * t1.re - x1i[e] * t1.im, i1 = x1r[e] * t1.im + x1i[e] * t1.re;
+            x0r[e] = r0; x0i[e] = i0; x1r[e] = r1; x1i[e] = i1;
+            t0 = cmul(t0, w1);
+            t1 = cmul(t1, w1);
+          }
+        }
+        const u4 s0r = {pk(x0r[0], x0r[1]), pk(x0r[2], x0r[3]), pk(x0r[4], x0r[5]), pk(x0r[6], x0r[7])};
+        const u4 s0i = {pk(x0i[0], x0i[1]), pk(x0i[2], x0i[3]), pk(x0i[4], x0i[5]), pk(x0i[6], x0i[7])};
+        const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
+        const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
+        const uint64_t o0 = (mb + f) * 512 + k0;
+        __builtin_nontemporal_store(s0r, reinterpret_cast<u4*>(c_re + o0));
+        __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(c_im + o0));
+        __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(c_re + o0 + 256));
+        __builtin_nontemporal_store(s1i, reinterpret_cast<u4*>(c_im + o0 + 256));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // D
+      continue;
+    }
 
     // ---- radix-2 combine at read-out: this thread takes 16-byte chunks (8 columns) of rows k and k + 256
     uint16_t* const o_re = a.out_re + bidx * a.out_stride;
@@ -778,8 +875,8 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     uint64_t av = 0;
     if (TW) {
       av = restb >> a.a_shift;
-      w_av = lookup<true>(a, av & a.t_mask);                                               // w_T^av (per unit of kprev)
-      w_half = lookup<true>(a, (av * ((a.ns * 256) & a.t_mask)) & a.t_mask);               // w_T^(av ns 256)
+      w_av = lookup<kLut512>(a, av & a.t_mask);                                            // w_T^av (per unit of kprev)
+      w_half = lookup<kLut512>(a, (av * ((a.ns * 256) & a.t_mask)) & a.t_mask);            // w_T^(av ns 256)
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -807,9 +904,9 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       if (TW) {
         // E = av (kprev + ns k') mod T; kprev of column e of this chunk = (kprev_f0 + e) >> inner_shift
         const uint64_t kprev_f0 = (mb + 8 * chunk) - (restb << a.ns_f_shift);
-        const cpx row0 = lookup<true>(a, (av * ((a.ns * k) & a.t_mask)) & a.t_mask);
+        const cpx row0 = lookup<kLut512>(a, (av * ((a.ns * k) & a.t_mask)) & a.t_mask);
         const cpx row1 = cmul(row0, w_half);
-        cpx col = lookup<true>(a, (av * ((kprev_f0 >> a.inner_shift) & a.t_mask)) & a.t_mask);
+        cpx col = lookup<kLut512>(a, (av * ((kprev_f0 >> a.inner_shift) & a.t_mask)) & a.t_mask);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const cpx t0 = cmul(col, row0), t1 = cmul(col, row1);

@@ -294,23 +294,26 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     a.a_shift = static_cast<uint32_t>(ilog2(p->n / (static_cast<uint64_t>(ps.next_radix) * ps.ns * radix)));
   }
   if (radix == 512) {
-    // plan creation only emits this pass where the geometry fits (pitch and ns_f multiples of 64, not the first pass)
-    static std::once_flag once[16];
-    hipError_t attr = hipSuccess;
-    std::call_once(once[p->device & 15], [&] {
-      attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWg512LdsBytes);
-      if (attr == hipSuccess)
-        attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWg512LdsBytes);
-    });
-    if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+    // plan creation only emits this pass where the geometry fits (pitch, and ns_f unless it is 1, multiples of 64)
+    const bool on_lanes = (a.ns_f == 1);
+    const void* fn = on_lanes ? (ps.tw_next ? reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsOnLanes, true>)
+                                            : reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsOnLanes, false>))
+                              : (ps.tw_next ? reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsInRegs, true>)
+                                            : reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsInRegs, false>));
+    TFFT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWg512LdsBytes));
     const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
-    if (ps.tw_next)
-      hipLaunchKernelGGL(colfft::colfft512_wg_kernel<true>, dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
-    else
-      hipLaunchKernelGGL(colfft::colfft512_wg_kernel<false>, dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+    if (on_lanes) {
+      if (ps.tw_next)
+        hipLaunchKernelGGL((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+      else
+        hipLaunchKernelGGL((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, false>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+    } else {
+      if (ps.tw_next)
+        hipLaunchKernelGGL((colfft::colfft512_wg_kernel<colfft::kColsInRegs, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+      else
+        hipLaunchKernelGGL((colfft::colfft512_wg_kernel<colfft::kColsInRegs, false>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+    }
     return TFFT_OK;
   }
   // default: stores straight from registers (8- / 16-byte pieces); variant bit 4096: stage the output through
@@ -622,18 +625,29 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     if (col_ok) n256 = lg / 8;
     int rem = lg - 8 * n256;
     std::vector<int> radices(n256, 256);
-    // Radix-512 column passes (never the first pass) where they save a whole pass: 2^17 = 256 x 512,
-    // 2^23 = 256 x 512 x 64, 2^25 = 256 x 256 x 512, 2^26 = 256 x 512 x 512. variant bit 8388608 turns them off.
-    const bool use512 = col_ok && inner == 1 && !(opts && (opts->variant & 8388608));
-    if (use512 && n256 >= 2 && rem == 1) {
-      radices[n256 - 1] = 512;
-      rem = 0;
-    } else if (use512 && n256 >= 3 && rem == 2) {
-      radices[n256 - 1] = radices[n256 - 2] = 512;
-      rem = 0;
-    } else if (use512 && n256 >= 2 && rem == 7) {
-      radices[n256 - 1] = 512;
-      rem = 6;
+    // Radix-512 column passes where they save a whole pass (2^15 = 512 x 64, 2^17 = 256 x 512, 2^18 = 512 x 512,
+    // 2^23 = 256 x 512 x 64, 2^25, 2^26 = 256 x 512 x 512, 2^27 = 512^3): the split lg = 8 a + 9 b + t, t <= 7, with the
+    // fewest passes (a tail of t bits costs 0 / 1 / 2 passes for t = 0 / 1..6 / 7); ties go to the fewest radix-512
+    // passes (their row segments are 128 bytes, not 256). variant bit 8388608 turns them off.
+    const bool use512 = col_ok && inner == 1 && lg >= 15 && !(opts && (opts->variant & 8388608));
+    if (use512) {
+      auto tail_cost = [](int t) { return t == 0 ? 0 : (t <= 6 ? 1 : 2); };
+      int best_a = n256, best_b = 0, best_cost = n256 + tail_cost(rem);
+      for (int b = 1; b <= 3; ++b)
+        for (int a2 = 0; 8 * a2 + 9 * b <= lg; ++a2) {
+          const int t = lg - 8 * a2 - 9 * b;
+          if (t > 7) continue;
+          const int cost = a2 + b + tail_cost(t);
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_a = a2;
+            best_b = b;
+          }
+        }
+      n256 = best_a + best_b;               // column passes in total
+      radices.assign(best_a, 256);
+      radices.insert(radices.end(), best_b, 512);
+      rem = lg - 8 * best_a - 9 * best_b;
     }
     for (; rem >= 4; rem -= 4) radices.push_back(16);
     if (rem) radices.push_back(1 << rem);

@@ -331,9 +331,9 @@ def test_narrow_pitch_cooperative_column_pass(tf, torch, orc, n, batch):
     _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_256)
 
 
-@pytest.mark.parametrize("lg,batch", [(17, 1), (17, 5), (23, 1), (25, 1)])
+@pytest.mark.parametrize("lg,batch", [(15, 3), (15, 64), (17, 1), (17, 5), (18, 2), (23, 1), (25, 1)])
 def test_radix512_column_pass(tf, torch, orc, lg, batch):
-    """2^17 = 256 x 512, 2^23 = 256 x 512 x 64, 2^25 = 256 x 256 x 512: the radix-512 column pass (two decimated radix-256
+    """2^15 = 512 x 64, 2^17 = 256 x 512, 2^18 = 512 x 512, 2^23 = 256 x 512 x 64, 2^25 = 256 x 256 x 512: the radix-512 column pass (two decimated radix-256
     halves + radix-2 combine at read-out, with and without the next pass's twiddles) against the oracle, and
     against the chain without it (variant bit 8388608), which must agree to fp16 rounding."""
     n = 1 << lg
@@ -624,7 +624,7 @@ def test_one_plan_from_several_host_threads(tf, torch):
         assert bool((g_ == w_).all())
 
 
-@pytest.mark.parametrize("lg", [8, 9, 11, 12, 13, 15, 16, 17, 18, 20, 21, 23, 25, 26])
+@pytest.mark.parametrize("lg", [8, 9, 11, 12, 13, 15, 16, 17, 18, 20, 21, 23, 25, 26, 27])
 def test_against_vendor_fft_on_device(tf, torch, lg):
     """Independent cross-check that needs no CPU oracle: hipFFT (through torch.fft, complex64) on the same fp16 input,
     the role cuFFT plays in the reference's tests (CuFFTTest.h:193-261). Large N run here in seconds."""
