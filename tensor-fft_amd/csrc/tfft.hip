@@ -300,7 +300,12 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
                                             : reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsOnLanes, false>))
                               : (ps.tw_next ? reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsInRegs, true>)
                                             : reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsInRegs, false>));
-    TFFT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWg512LdsBytes));
+    static std::once_flag once[4][16];   // per kernel form and device: opt in to the 144 KiB of LDS
+    hipError_t attr = hipSuccess;
+    std::call_once(once[(on_lanes ? 2 : 0) + (ps.tw_next ? 1 : 0)][p->device & 15], [&] {
+      attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWg512LdsBytes);
+    });
+    if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
     const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
     if (on_lanes) {
