@@ -1,0 +1,248 @@
+// k4096r.hpp — batched N = 4096 R (R = 2, 4, 8: N = 8192, 16384, 32768) fp16 C2C FFT for gfx950 in ONE pass over HBM.
+//
+// The reference runs these lengths as TensorFFT4096 per 4096-point block followed by log2(R) radix-2 launches per
+// transform (src/base/ComputeFFT.h:72-145, Radix2.cu:20-77), i.e. 1 + log2(R) round trips through global memory;
+// this library's own multi-pass plan needs two (radix-256/512 column pass + tail). Here R waves share one transform
+// and the radix-R step comes FIRST, on the way from LDS into the stage-1 operands (decimation in frequency):
+//
+//   n = m + 4096 r  (r < R),   k = R kk + s  (s < R)
+//   u_s[m] = w_N^(m s) / (2 R)  sum_r x[m + 4096 r] w_R^(r s)       (fp32, rounded once to binary16; the extra 1/2 is
+//                                                                    headroom for the rotation, returned after stage 2)
+//   X[R kk + s] = DFT_4096(u_s)[kk] / 4096                           (the three MFMA stages of k4096.hpp, unchanged)
+//
+// Wave s of a group copies block s (4096 contiguous points, one LDS-DMA stream, the 4096 kernel's swizzled image) into
+// its own 16-KiB LDS region; after a workgroup barrier every wave reads the same tile of ALL R regions, forms its own
+// combination u_s in fp32 (R complex multiply-adds with w_R^(rs)/R, then the twiddle w_N^(m s) = a per-lane constant
+// times a per-tile recurrence), and feeds stage 1. Stages 2 and 3 are those of the 4096 kernel. The R spectra are
+// staged in the R regions and read out interleaved (X[R kk + s]: 8 / R consecutive kk from each of the R images make
+// one 16-byte store), so global traffic is full 1-KiB rows in both directions. Four workgroup barriers per transform.
+// LDS reads are amplified R x (every wave reads all R blocks), VALU work grows by about 10 R operations per tile.
+#pragma once
+
+#include "k4096.hpp"
+
+namespace k4096r {
+
+using namespace k4096;
+
+template <int R>
+__global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* in_re, const uint16_t* in_im,
+                                                               uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
+                                                               uint64_t out_stride, uint32_t batch,
+                                                               const uint8_t* __restrict__ tables) {
+  constexpr int kGroups = kWavesPerBlock / R;      // transforms per workgroup iteration
+  constexpr int kN = 4096 * R;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave / R, s = wave % R;
+
+  for (int i = tid; i < kLdsTableBytes / 16; i += kThreads)
+    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(tables + kOffG)[i];
+  const h8 f_re = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32);
+  const h8 f_im = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32 + 16);
+  // (x 2: gives back the headroom factor of the front end after two averaging MFMA stages, exact in fp32)
+  const f4 tw_re = 2.0f * *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
+  const f4 tw_im = 2.0f * *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  uint8_t* const wl = lds + kLdsTableBytes + wave * kLdsWaveBytes;                 // this wave's region
+  uint8_t* const gl = lds + kLdsTableBytes + (grp * R) * kLdsWaveBytes;            // region of the group's block 0
+  const uint32_t wl_off = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)wl)));
+  const uint8_t* const g_tab = lds + lane * 16;
+  const uint8_t* const h_tab = lds + 16384 + lane * 16;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int mrow = q + 4 * (g & 1), bb = g >> 1;
+  const uint8_t* const tr_base = gl + mrow * 1024 + bb * 512 + 8 * p;              // + r * 16 KiB for block r
+
+  // ---- constants of the radix-R front end
+  // c[r] = w_R^(r s) / R;  pt[j] = w_N^(s (n0 + 256 sigma(g, j))), n0 = lane & 15;  qstep = w_N^(16 s) (per tile n1)
+  // (v_cos / v_sin take revolutions; their ~1e-6 absolute error is three orders below binary16's resolution. The
+  // eighth roots of unity are exact constants. libm's sincospif here cost ~100 VGPRs of prologue pressure and spills.)
+  float c_re[R], c_im[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e8 = ((r * s) % R) * (8 / R);                    // w_8^e8
+    const float h = 0.70710678118654752f;
+    const float cs = (e8 == 0) ? 1.f : (e8 == 4) ? -1.f : (e8 == 2 || e8 == 6) ? 0.f : (e8 == 1 || e8 == 7) ? h : -h;
+    const float sn = (e8 == 0 || e8 == 4) ? 0.f : (e8 == 2) ? -1.f : (e8 == 6) ? 1.f : (e8 == 1 || e8 == 3) ? -h : h;
+    c_re[r] = cs / (2 * R);     // 1 / R of the butterfly and a factor 1/2 of headroom: the rotation by w_N^(m s) below can
+    c_im[r] = sn / (2 * R);     // grow a component of a full-scale input by sqrt 2 before it is rounded to binary16
+  }
+  float pt_re[4], pt_im[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float rev = static_cast<float>(s * ((lane & 15) + 256 * sigma(g, j))) * (1.0f / kN);   // exact: < 2^15 / 2^15
+    pt_re[j] = __builtin_amdgcn_cosf(rev);
+    pt_im[j] = -__builtin_amdgcn_sinf(rev);
+  }
+  const float qs_re = __builtin_amdgcn_cosf(static_cast<float>(16 * s) * (1.0f / kN));
+  const float qs_im = -__builtin_amdgcn_sinf(static_cast<float>(16 * s) * (1.0f / kN));
+
+  const uint32_t out_chunk = 4096u * s;     // this wave stores halves [4096 s, 4096 (s + 1)) of each output plane
+
+  const uint32_t groups_total = (batch + kGroups - 1) / kGroups;
+  for (uint32_t it = blockIdx.x; it < groups_total; it += gridDim.x) {
+    // a group past the end of the batch re-does the last transform (it keeps the barriers uniform) without storing
+    const uint32_t b_raw = it * kGroups + grp;
+    const bool live = b_raw < batch;
+    const uint32_t b = live ? b_raw : batch - 1;
+    dma_in<true>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(b) * in_stride + 4096 * s),
+                 reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(b) * in_stride + 4096 * s), wl_off, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // A: all R blocks of every group's transform are in LDS
+
+    // ---- radix-R front end + stage 1: D1_n1[k0 = 4g + r][n0 = lane & 15], packed over tile pairs
+    uint32_t pr[8][4], pi[8][4];
+    float q_re = 1.f, q_im = 0.f;            // w_N^(16 s n1)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f4 dre[2], dim[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int n1 = 2 * t + e;
+        float a_re[4] = {0.f, 0.f, 0.f, 0.f}, a_im[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint8_t* ad = tr_base + r * kLdsWaveBytes + 32 * (n1 ^ mrow);
+          const s4 xr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad));
+          const s4 xi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad + 8192));
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          const h4 hr = __builtin_bit_cast(h4, xr), hi = __builtin_bit_cast(h4, xi);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float vr = static_cast<float>(hr[j]), vi = static_cast<float>(hi[j]);
+            a_re[j] = __builtin_fmaf(vr, c_re[r], __builtin_fmaf(-vi, c_im[r], a_re[j]));
+            a_im[j] = __builtin_fmaf(vr, c_im[r], __builtin_fmaf(vi, c_re[r], a_im[j]));
+          }
+        }
+        float u_re[4], u_im[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float w_re = __builtin_fmaf(pt_re[j], q_re, -(pt_im[j] * q_im));
+          const float w_im = __builtin_fmaf(pt_re[j], q_im, pt_im[j] * q_re);
+          u_re[j] = __builtin_fmaf(a_re[j], w_re, -(a_im[j] * w_im));
+          u_im[j] = __builtin_fmaf(a_re[j], w_im, a_im[j] * w_re);
+        }
+        const u4 raw = {pk(u_re[0], u_re[1]), pk(u_re[2], u_re[3]), pk(u_im[0], u_im[1]), pk(u_im[2], u_im[3])};
+        const h8 xop = __builtin_bit_cast(h8, raw);
+        dre[e] = mfma(f_re, xop);
+        dim[e] = mfma(f_im, xop);
+        const float nq_re = __builtin_fmaf(q_re, qs_re, -(q_im * qs_im));
+        const float nq_im = __builtin_fmaf(q_re, qs_im, q_im * qs_re);
+        q_re = nq_re;
+        q_im = nq_im;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[t][r] = pk(dre[0][r], dre[1][r]);
+        pi[t][r] = pk(dim[0][r], dim[1][r]);
+      }
+      // keep the scheduler from hoisting every tile's 2 R transposed reads to the top of the loop (it did: 256 VGPRs
+      // and scratch spills); one tile pair in flight is enough with two waves per SIMD
+      asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // B: the input images have been consumed by every wave
+
+    // ---- n1 high bits (register index) <-> k0 high bits (lane group), as in the 4096 kernel
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        transpose4(pr[0 + pp][r], pr[2 + pp][r], pr[4 + pp][r], pr[6 + pp][r]);
+        transpose4(pi[0 + pp][r], pi[2 + pp][r], pi[4 + pp][r], pi[6 + pp][r]);
+      }
+
+    // ---- stages 2 and 3 tile by tile; the spectrum of u_s is staged in this wave's region in natural order
+    auto tile23 = [&](int k0, f4& o_re, f4& o_im) {
+      const int a = k0 >> 2, r = k0 & 3;
+      const u4 araw = {pr[2 * a][r], pr[2 * a + 1][r], pi[2 * a][r], pi[2 * a + 1][r]};
+      const h8 aop = __builtin_bit_cast(h8, araw);
+      const u4 graw = *reinterpret_cast<const u4*>(g_tab + k0 * 1024);
+      const f4 e_re = mfma(aop, __builtin_bit_cast(h8, graw));
+      const f4 e_im = mfma(aop, im_form(graw));
+      f4 t_re, t_im;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        t_re[r4] = __builtin_fmaf(e_re[r4], tw_re[r4], -(e_im[r4] * tw_im[r4]));
+        t_im[r4] = __builtin_fmaf(e_re[r4], tw_im[r4], e_im[r4] * tw_re[r4]);
+      }
+      const u4 braw = {pk(t_re[0], t_re[1]), pk(t_re[2], t_re[3]), pk(t_im[0], t_im[1]), pk(t_im[2], t_im[3])};
+      const h8 bop = __builtin_bit_cast(h8, braw);
+      const u4 hraw = *reinterpret_cast<const u4*>(h_tab + k0 * 1024);
+      o_re = mfma(__builtin_bit_cast(h8, hraw), bop);   // o[r2] = U_s[k0 + 16 k1 + 256 (4g + r2)]
+      o_im = mfma(im_form(hraw), bop);
+    };
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint32_t ore[4][4], oim[4][4];
+#pragma unroll
+      for (int kp = 0; kp < 4; ++kp) {
+        f4 e_re, e_im, o_re, o_im;
+        tile23(8 * half + 2 * kp, e_re, e_im);
+        tile23(8 * half + 2 * kp + 1, o_re, o_im);
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {
+          ore[r2][kp] = pk(e_re[r2], o_re[r2]);
+          oim[r2][kp] = pk(e_im[r2], o_im[r2]);
+        }
+      }
+#pragma unroll
+      for (int r2 = 0; r2 < 4; ++r2) {
+        // 16-byte slot 2 k1 + half of row 4g + r2 (512 B per row of 256 kk); plain layout: the interleaving
+        // read-out below touches 2-, 4- or 8-byte pieces, so the 4096 kernel's slot swizzle is not used here
+        const uint32_t off = 16u * (2u * (lane & 15) + half) + 512u * (4 * g + r2);
+        *reinterpret_cast<u4*>(wl + off) = u4{ore[r2][0], ore[r2][1], ore[r2][2], ore[r2][3]};
+        *reinterpret_cast<u4*>(wl + 8192 + off) = u4{oim[r2][0], oim[r2][1], oim[r2][2], oim[r2][3]};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // C: the R spectra of every group are staged
+
+    // ---- interleaved read-out: X[R kk + s'] ; this wave stores output halves [4096 s, 4096 (s + 1)) of both planes
+    uint16_t* const f_out_re = out_re + static_cast<uint64_t>(b) * out_stride + out_chunk;
+    uint16_t* const f_out_im = out_im + static_cast<uint64_t>(b) * out_stride + out_chunk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t idx0 = out_chunk + 512u * i + 8u * lane;   // first output index of this lane's 16 bytes
+      const uint32_t kk0 = idx0 / R;                            // 8 / R consecutive kk from each image
+      u4 vr, vi;
+      if (R == 2) {
+        const u2 a0 = *reinterpret_cast<const u2*>(gl + 2 * kk0), a1 = *reinterpret_cast<const u2*>(gl + kLdsWaveBytes + 2 * kk0);
+        const u2 b0 = *reinterpret_cast<const u2*>(gl + 8192 + 2 * kk0), b1 = *reinterpret_cast<const u2*>(gl + kLdsWaveBytes + 8192 + 2 * kk0);
+        vr = u4{(a0.x & 0xffffu) | (a1.x << 16), (a0.x >> 16) | (a1.x & 0xffff0000u), (a0.y & 0xffffu) | (a1.y << 16), (a0.y >> 16) | (a1.y & 0xffff0000u)};
+        vi = u4{(b0.x & 0xffffu) | (b1.x << 16), (b0.x >> 16) | (b1.x & 0xffff0000u), (b0.y & 0xffffu) | (b1.y << 16), (b0.y >> 16) | (b1.y & 0xffff0000u)};
+      } else if (R == 4) {
+        uint32_t pa[4], pb[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          pa[s2] = *reinterpret_cast<const uint32_t*>(gl + s2 * kLdsWaveBytes + 2 * kk0);
+          pb[s2] = *reinterpret_cast<const uint32_t*>(gl + s2 * kLdsWaveBytes + 8192 + 2 * kk0);
+        }
+        vr = u4{(pa[0] & 0xffffu) | (pa[1] << 16), (pa[2] & 0xffffu) | (pa[3] << 16), (pa[0] >> 16) | (pa[1] & 0xffff0000u), (pa[2] >> 16) | (pa[3] & 0xffff0000u)};
+        vi = u4{(pb[0] & 0xffffu) | (pb[1] << 16), (pb[2] & 0xffffu) | (pb[3] << 16), (pb[0] >> 16) | (pb[1] & 0xffff0000u), (pb[2] >> 16) | (pb[3] & 0xffff0000u)};
+      } else {
+        uint32_t pa[8], pb[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          pa[s2] = *reinterpret_cast<const uint16_t*>(gl + s2 * kLdsWaveBytes + 2 * kk0);
+          pb[s2] = *reinterpret_cast<const uint16_t*>(gl + s2 * kLdsWaveBytes + 8192 + 2 * kk0);
+        }
+        vr = u4{pa[0] | (pa[1] << 16), pa[2] | (pa[3] << 16), pa[4] | (pa[5] << 16), pa[6] | (pa[7] << 16)};
+        vi = u4{pb[0] | (pb[1] << 16), pb[2] | (pb[3] << 16), pb[4] | (pb[5] << 16), pb[6] | (pb[7] << 16)};
+      }
+      if (live) {
+        __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(f_out_re + 512 * i + 8 * lane));
+        __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(f_out_im + 512 * i + 8 * lane));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // D: the staged spectra have been read; regions may be refilled
+  }
+}
+
+}  // namespace k4096r

@@ -19,6 +19,7 @@
 #include "k4096.hpp"
 #include "k256.hpp"
 #include "k256r.hpp"
+#include "k4096r.hpp"
 #include "colfft.hpp"
 #include "permute.hpp"
 #include "stockham.hpp"
@@ -47,7 +48,7 @@ inline int ilog2(uint64_t x) {
   return l;
 }
 
-enum class PassKind { K4096, K256, K256R, Col256, Stockham };
+enum class PassKind { K4096, K4096R, K256, K256R, Col256, Stockham };
 
 struct Pass {
   PassKind kind;
@@ -83,7 +84,7 @@ namespace {
 // plans that are one LDS-resident kernel (no ping-pong chain, no workspace, no autosort twiddle tables)
 inline bool single_kernel(const tfft_plan* p) {
   return p->passes.size() == 1 && (p->passes[0].kind == PassKind::K4096 || p->passes[0].kind == PassKind::K256 ||
-                                   p->passes[0].kind == PassKind::K256R);
+                                   p->passes[0].kind == PassKind::K256R || p->passes[0].kind == PassKind::K4096R);
 }
 
 // Grid of a grid-stride ("persistent") kernel whose workgroups each own `iters` work items per wave slot: at least one
@@ -178,6 +179,38 @@ int launch_k256r(const tfft_plan* p, int radix, const void* in_re, const void* i
     default:
       return direct ? launch_k256r_t<8, false>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s)
                     : launch_k256r_t<8, true>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
+  }
+}
+
+template <int R>
+int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                    uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
+  static std::once_flag once[16];
+  hipError_t attr = hipSuccess;
+  std::call_once(once[p->device & 15], [&] {
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k4096r::fft4096r_kernel<R>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, k4096::kLdsBytes);
+  });
+  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+  const uint32_t per_wg = k4096::kWavesPerBlock / R;      // transforms per workgroup iteration
+  const uint32_t blocks_needed = static_cast<uint32_t>((p->batch + per_wg - 1) / per_wg);
+  // persistent workgroups: with four workgroup barriers per transform the short-lived launch shape of the 4096
+  // kernel does not help here (measured at 2^13: 405 / 425 / 440 / 457 Gsamples/s for 1 / 2 / 4 / all iterations)
+  static const uint32_t iters = env_iters("TFFT_K4096R_ITERS", 1000000);   // experiment knob
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
+  hipLaunchKernelGGL(k4096r::fft4096r_kernel<R>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+                     static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
+  return TFFT_OK;
+}
+
+int launch_k4096r(const tfft_plan* p, int radix, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                  uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
+  switch (radix) {
+    case 2: return launch_k4096r_t<2>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
+    case 4: return launch_k4096r_t<4>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
+    default: return launch_k4096r_t<8>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
   }
 }
 
@@ -435,6 +468,8 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
     const PassKind kind = p->passes[0].kind;
     const int rc = kind == PassKind::K4096
                        ? launch_k4096(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s)
+                   : kind == PassKind::K4096R
+                       ? launch_k4096r(p, p->passes[0].radix, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s)
                        : (kind == PassKind::K256
                               ? launch_k256(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s)
                               : launch_k256r(p, p->passes[0].radix, in_re, in_im, out_re, out_im, p->in_stride,
@@ -613,6 +648,12 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     need_tables = true;
   } else if (n == 256 && inner == 1 && !force_stockham) {
     p->passes.push_back(Pass{PassKind::K256, 256, 1, false, false, 0});
+    need_tables = true;
+  } else if ((n == 8192 || n == 16384 || n == 32768) && inner == 1 && !force_stockham &&
+             !(opts && (opts->variant & 16777216))) {
+    // one pass: R waves share a transform, radix-R step in front of the 4096 kernel's stages (variant bit 16777216:
+    // the multi-pass column plan instead)
+    p->passes.push_back(Pass{PassKind::K4096R, static_cast<int>(n / 4096), 1, false, false, 0});
     need_tables = true;
   } else if ((n == 512 || n == 1024 || n == 2048) && inner == 1 && !force_stockham) {
     const int R = static_cast<int>(n / 256);
@@ -945,6 +986,7 @@ const char* tfft_plan_kernel_name(const tfft_plan* p) {
     case PassKind::K4096: return "fft4096_kernel";
     case PassKind::K256: return "fft256_kernel";
     case PassKind::K256R: return "fft256r_kernel";
+    case PassKind::K4096R: return "fft4096r_kernel";
     case PassKind::Col256: return "colfft256_kernel";
     default: return "pass_kernel";
   }
@@ -961,7 +1003,7 @@ double tfft_plan_mfma_flops(const tfft_plan* p) {
   // one radix-16 MFMA stage = 16 tiles x 2 MFMA(16x16x32) x 16384 flop per 4096 samples = 128 flop/sample
   double stages = 0;
   for (const Pass& ps : p->passes)
-    stages += ps.kind == PassKind::K4096 ? 3 : ((ps.kind == PassKind::Col256 || ps.kind == PassKind::K256 || ps.kind == PassKind::K256R) ? 2 : 0);
+    stages += (ps.kind == PassKind::K4096 || ps.kind == PassKind::K4096R) ? 3 : ((ps.kind == PassKind::Col256 || ps.kind == PassKind::K256 || ps.kind == PassKind::K256R) ? 2 : 0);
   return 128.0 * stages * static_cast<double>(p->n) * static_cast<double>(p->inner) * static_cast<double>(p->batch);
 }
 

@@ -14,6 +14,16 @@ pytestmark = pytest.mark.gpu
                                             (1 << 13, 515, 1), (1 << 14, 255, 1),    # narrow column pass + ragged remainder, radix-32/64 tails
                                             (1 << 15, 64, 1), (1 << 21, 4, 1), (1 << 17, 32, 1)])
 def test_repeated_runs_are_bit_identical(n, batch, inner):
+    _repeat(n, batch, inner, 0)
+
+
+@pytest.mark.parametrize("n,batch", [(1 << 13, 515), (1 << 14, 255), (1 << 15, 64)])
+def test_repeated_runs_of_the_column_plan_are_bit_identical(n, batch):
+    """2^13..2^15 default to the single-pass kernel; variant bit 16777216 selects the column-pass plan they used before."""
+    _repeat(n, batch, 1, 16777216)
+
+
+def _repeat(n, batch, inner, variant):
     import torch
     import __graft_entry__ as g
 
@@ -22,7 +32,7 @@ def test_repeated_runs_are_bit_identical(n, batch, inner):
 
     gen = torch.Generator(device="cuda").manual_seed(n + inner)
     x = (torch.rand(batch * 2 * n * inner, device="cuda", generator=gen) * 2 - 1).half()
-    plan = tf.TfftPlan(n, batch, 0, inner=inner, preserve_input=True)
+    plan = tf.TfftPlan(n, batch, 0, inner=inner, preserve_input=True, variant=variant)
     ref = None
     for _ in range(25):
         y = torch.zeros_like(x)

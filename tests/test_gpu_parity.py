@@ -325,10 +325,35 @@ def test_narrow_pitch_cooperative_column_pass(tf, torch, orc, n, batch):
     rng = np.random.default_rng(n + batch)
     re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
     im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
-    gr, gi = _run(tf, torch, re, im)
-    pr, pi = _run(tf, torch, re, im, variant=131072)
+    gr, gi = _run(tf, torch, re, im, variant=16777216)            # the column plan (default is the single-pass kernel)
+    pr, pi = _run(tf, torch, re, im, variant=16777216 | 131072)
     assert np.array_equal(gr.view(np.uint16), pr.view(np.uint16)) and np.array_equal(gi.view(np.uint16), pi.view(np.uint16))
     _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_256)
+
+
+@pytest.mark.parametrize("n", [8192, 16384, 32768])
+@pytest.mark.parametrize("batch", [1, 3, 4, 9, 130])
+def test_n4096r_single_pass_kernel(tf, torch, orc, n, batch):
+    """N = 8192 / 16384 / 32768 as ONE kernel (R = N / 4096 waves share a transform: radix-R front end in fp32, the
+    4096 kernel's three MFMA stages, interleaved read-out); ragged last workgroup, in place, strides."""
+    rng = np.random.default_rng(n + batch)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    plan = tf.TfftPlan(n, batch, 0)
+    assert plan.kernel_name == "fft4096r_kernel" and plan.num_launches == 1 and plan.workspace_bytes == 0
+    gr, gi = _run(tf, torch, re, im)
+    _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_4096)
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    plan.exec(dev, dev[n:], dev, dev[n:])
+    torch.cuda.synchronize()
+    o = dev.cpu().numpy().reshape(batch, 2, n)
+    assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16)) and np.array_equal(o[:, 1].view(np.uint16), gi.view(np.uint16))
+    d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
+    o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
+    tf.TfftPlan(n, batch, 0, in_batch_stride=n, out_batch_stride=n).exec(d_re, d_im, o_re, o_im)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_re.cpu().numpy().reshape(batch, n).view(np.uint16), gr.view(np.uint16))
+    assert np.array_equal(o_im.cpu().numpy().reshape(batch, n).view(np.uint16), gi.view(np.uint16))
 
 
 @pytest.mark.parametrize("lg,batch", [(15, 3), (15, 64), (17, 1), (17, 5), (18, 2), (23, 1), (25, 1)])
@@ -340,15 +365,16 @@ def test_radix512_column_pass(tf, torch, orc, lg, batch):
     rng = np.random.default_rng(lg + batch)
     re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
     im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
-    plan = tf.TfftPlan(n, batch, 0)
-    other = tf.TfftPlan(n, batch, 0, variant=8388608)
+    multi = 16777216 if lg <= 15 else 0          # 2^13..2^15 default to the single-pass kernel: ask for the column plan
+    plan = tf.TfftPlan(n, batch, 0, variant=multi)
+    other = tf.TfftPlan(n, batch, 0, variant=multi | 8388608)
     assert plan.num_launches == other.num_launches - 1
-    gr, gi = _run(tf, torch, re, im)
+    gr, gi = _run(tf, torch, re, im, variant=multi)
     exact = _c(*orc.dft64(re, im))
     got = _c(gr, gi)
     assert np.isfinite(got).all()
     assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL
-    pr, pi = _run(tf, torch, re, im, variant=8388608)
+    pr, pi = _run(tf, torch, re, im, variant=multi | 8388608)
     ref = _c(pr, pi)
     assert np.abs(got - exact).max() <= 1.5 * np.abs(ref - exact).max() + 2.0 ** -11 * np.abs(exact).max()
 
