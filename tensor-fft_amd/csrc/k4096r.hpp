@@ -25,6 +25,8 @@ namespace k4096r {
 
 using namespace k4096;
 
+// (Tried: two independent 4-wave workgroups per CU with the G table read from global memory instead of LDS, so that one
+// workgroup computes while the other waits for memory: 2^13 487 -> 456 Gsamples/s, 2^14 435 -> 445; not kept.)
 template <int R>
 __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                                uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
@@ -112,11 +114,22 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
           const s4 xi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad + 8192));
           typedef _Float16 h4 __attribute__((ext_vector_type(4)));
           const h4 hr = __builtin_bit_cast(h4, xr), hi = __builtin_bit_cast(h4, xi);
+          if constexpr (R == 2) {        // w_2^(r s) = +-1: two multiply-adds per sample
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float vr = static_cast<float>(hr[j]), vi = static_cast<float>(hi[j]);
-            a_re[j] = __builtin_fmaf(vr, c_re[r], __builtin_fmaf(-vi, c_im[r], a_re[j]));
-            a_im[j] = __builtin_fmaf(vr, c_im[r], __builtin_fmaf(vi, c_re[r], a_im[j]));
+            for (int j = 0; j < 4; ++j) {
+              a_re[j] = __builtin_fmaf(static_cast<float>(hr[j]), c_re[r], a_re[j]);
+              a_im[j] = __builtin_fmaf(static_cast<float>(hi[j]), c_re[r], a_im[j]);
+            }
+          } else {
+            // general complex multiply-add, also for the +-1 / +-i roots: choosing the cheaper form per (r, s) needs
+            // wave-uniform branches inside this loop, which cost far more than they save (2^14: 415 -> 339
+            // Gsamples/s, 2^15: 340 -> 247 when tried)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float vr = static_cast<float>(hr[j]), vi = static_cast<float>(hi[j]);
+              a_re[j] = __builtin_fmaf(vr, c_re[r], __builtin_fmaf(-vi, c_im[r], a_re[j]));
+              a_im[j] = __builtin_fmaf(vr, c_im[r], __builtin_fmaf(vi, c_re[r], a_im[j]));
+            }
           }
         }
         float u_re[4], u_im[4];
