@@ -91,7 +91,7 @@ int tfft_max_no_optin_shared_mem(int device_id);
  * it owns small device-side constant tables (and a workspace if it allocated one).
  * A plan with tfft_plan_workspace_bytes() > 0 has ONE workspace: executions of such a plan
  * must not overlap in time (same stream, or one plan per stream). Single-pass plans
- * (N <= 4096 with a contiguous axis) have no such restriction. */
+ * (N <= 32768 with a contiguous axis) have no such restriction. */
 typedef struct tfft_plan_opts {
   uint64_t in_batch_stride;
   uint64_t out_batch_stride;
@@ -106,7 +106,7 @@ typedef struct tfft_plan_opts {
                            these (default = 2|8); 4 and 64 are timing-only (WRONG results).
                            Any N: 32 = plain autosort chain (no column kernel); 2097152 = do not fuse the
                            radix-16 + radix-2/4 tail into one radix-32/64 pass; 8388608 = no radix-512 column
-                           passes; 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
+                           passes; 16777216 = N = 8192..32768 as a column plan instead of the single-pass kernel; 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
                            Column passes: 131072 = per-wave kernel, 524288 = 4-wave cooperative workgroups,
                            262144 = no non-temporal accesses, 1048576 = 16-byte stores straight from registers,
                            4096 / 8192 = per-wave kernel with LDS-staged stores / hardware sin-cos twiddles.
@@ -119,7 +119,7 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
 void tfft_plan_destroy(tfft_plan* plan);
 
 /* Number of passes over the data one tfft_exec makes (= kernel launches, except that a narrow column pass with a
- * ragged batch takes two) and the bytes of device scratch it needs beyond in/out (0 for N <= 4096). If nonzero, either hand memory in
+ * ragged batch takes two) and the bytes of device scratch it needs beyond in/out (0 for N <= 32768 with a contiguous axis). If nonzero, either hand memory in
  * with tfft_plan_set_workspace() or let the first tfft_exec hipMalloc it. */
 int tfft_plan_num_launches(const tfft_plan* plan);
 size_t tfft_plan_workspace_bytes(const tfft_plan* plan);
