@@ -43,7 +43,15 @@ def main():
         y = torch.empty_like(x)
         # 0 = library default (10 at N = 4096); 32 = plain autosort chain; 524288 = 4-wave cooperative column
         # workgroups; 2097152 = unfused radix-16 + radix-2/4 tail; 1048576 = unstaged column stores
-        cands = [16, 2, 10, 8, 1] if n == 4096 else ([0, 32] if n < 8192 else [0, 32, 524288, 2097152, 1048576])
+        # 16777216 = column plan instead of the single-pass kernel (2^13..2^15); 8388608 = no radix-512 column passes
+        if n == 4096:
+            cands = [16, 2, 10, 8, 1]
+        elif n < 8192:
+            cands = [0, 32]
+        elif n <= 32768:
+            cands = [0, 16777216, 16777216 | 8388608, 32]
+        else:
+            cands = [0, 32, 524288, 2097152, 1048576, 8388608]
         best = None
         for v in cands:
             try:
