@@ -11,15 +11,18 @@
 //   X[R kk + s] = DFT_4096(u_s)[kk] / 4096                           (the three MFMA stages of k4096.hpp, unchanged)
 //
 // Wave s of a group copies block s (4096 contiguous points, one LDS-DMA stream, the 4096 kernel's swizzled image) into
-// its own 16-KiB LDS region; after a workgroup barrier every wave reads the same tile of ALL R regions, forms its own
-// combination u_s in fp32 (R complex multiply-adds with w_R^(rs)/R, then the twiddle w_N^(m s) = a per-lane constant
-// times a per-tile recurrence), and feeds stage 1. Stages 2 and 3 are those of the 4096 kernel. The R spectra are
-// staged in the R regions and read out interleaved (X[R kk + s]: 8 / R consecutive kk from each of the R images make
-// one 16-byte store), so global traffic is full 1-KiB rows in both directions. Four workgroup barriers per transform.
-// LDS reads are amplified R x (every wave reads all R blocks), VALU work grows by about 10 R operations per tile.
+// its own 16-KiB LDS region. After a workgroup barrier the group does the radix-R butterfly IN PLACE across its R
+// regions: every wave owns 1/R of the sample positions, reads the R samples x[m + 4096 r] of each, computes all R
+// outputs (DFT_R in registers, twiddles w_N^(m s) as powers of w_N^m, one rounding to binary16) and writes u_s[m] back to
+// region s at the same position. Region s then holds u_s in exactly the image the 4096 kernel expects, and stages 1-3
+// are that kernel's. The R spectra are staged in the R regions and read out interleaved (X[R kk + s]: 8 / R consecutive
+// kk from each of the R images make one 16-byte store), so global traffic is full 1-KiB rows in both directions.
+// Four workgroup barriers per transform. (A first version let every wave read all R blocks per stage-1 tile and form only
+// its own u_s: R x the LDS reads and 2.3-3 x the arithmetic per sample; 2^15 ran at 350 Gsamples/s with it.)
 #pragma once
 
 #include "k4096.hpp"
+#include "stockham.hpp"
 
 namespace k4096r {
 
@@ -58,31 +61,11 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   const uint8_t* const h_tab = lds + 16384 + lane * 16;
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
   const int mrow = q + 4 * (g & 1), bb = g >> 1;
-  const uint8_t* const tr_base = gl + mrow * 1024 + bb * 512 + 8 * p;              // + r * 16 KiB for block r
+  const uint8_t* const tr_base = wl + mrow * 1024 + bb * 512 + 8 * p;
 
-  // ---- constants of the radix-R front end
-  // c[r] = w_R^(r s) / R;  pt[j] = w_N^(s (n0 + 256 sigma(g, j))), n0 = lane & 15;  qstep = w_N^(16 s) (per tile n1)
-  // (v_cos / v_sin take revolutions; their ~1e-6 absolute error is three orders below binary16's resolution. The
-  // eighth roots of unity are exact constants. libm's sincospif here cost ~100 VGPRs of prologue pressure and spills.)
-  float c_re[R], c_im[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int e8 = ((r * s) % R) * (8 / R);                    // w_8^e8
-    const float h = 0.70710678118654752f;
-    const float cs = (e8 == 0) ? 1.f : (e8 == 4) ? -1.f : (e8 == 2 || e8 == 6) ? 0.f : (e8 == 1 || e8 == 7) ? h : -h;
-    const float sn = (e8 == 0 || e8 == 4) ? 0.f : (e8 == 2) ? -1.f : (e8 == 6) ? 1.f : (e8 == 1 || e8 == 3) ? -h : h;
-    c_re[r] = cs / (2 * R);     // 1 / R of the butterfly and a factor 1/2 of headroom: the rotation by w_N^(m s) below can
-    c_im[r] = sn / (2 * R);     // grow a component of a full-scale input by sqrt 2 before it is rounded to binary16
-  }
-  float pt_re[4], pt_im[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float rev = static_cast<float>(s * ((lane & 15) + 256 * sigma(g, j))) * (1.0f / kN);   // exact: < 2^15 / 2^15
-    pt_re[j] = __builtin_amdgcn_cosf(rev);
-    pt_im[j] = -__builtin_amdgcn_sinf(rev);
-  }
-  const float qs_re = __builtin_amdgcn_cosf(static_cast<float>(16 * s) * (1.0f / kN));
-  const float qs_im = -__builtin_amdgcn_sinf(static_cast<float>(16 * s) * (1.0f / kN));
+  // ---- constant of the radix-R front end: w_N^1 (v_cos / v_sin take revolutions; their ~1e-6 absolute error is three
+  // orders below binary16's resolution)
+  const float st_re = __builtin_amdgcn_cosf(1.0f / kN), st_im = -__builtin_amdgcn_sinf(1.0f / kN);
 
   const uint32_t out_chunk = 4096u * s;     // this wave stores halves [4096 s, 4096 (s + 1)) of each output plane
 
@@ -97,69 +80,99 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // A: all R blocks of every group's transform are in LDS
 
-    // ---- radix-R front end + stage 1: D1_n1[k0 = 4g + r][n0 = lane & 15], packed over tile pairs
+    // ---- radix-R front end, IN PLACE across the group's R regions: this wave owns 8 / R chunks per lane (16 bytes =
+    // 8 consecutive m) of every block, so each sample is read once and each u_s[m] written once; no other wave
+    // touches these positions, hence no barrier inside. Region s ends up holding u_s in the 4096 kernel's image.
+#pragma unroll
+    for (int ps = 0; ps < 8 / R; ++ps) {
+      const int mm = s * (8 / R) + ps;                               // 1-KiB block of the plane: chunks 64 mm .. 64 mm + 63
+      const uint32_t slot = mm * 1024 + 16 * (lane ^ (2 * mm));      // LDS slot of global chunk c = 64 mm + lane
+      const float rev0 = static_cast<float>(8 * (64 * mm + lane)) * (1.0f / kN);   // m0 / N, exact
+      float w1_re = __builtin_amdgcn_cosf(rev0), w1_im = -__builtin_amdgcn_sinf(rev0);   // w_N^m, m = m0 + e
+      // (plain dword arrays: __builtin_bit_cast applied directly to an element of an ext-vector reads element 0)
+      uint32_t in_r[R][4], in_i[R][4];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const u4 vr = *reinterpret_cast<const u4*>(gl + r * kLdsWaveBytes + slot);
+        const u4 vi = *reinterpret_cast<const u4*>(gl + r * kLdsWaveBytes + 8192 + slot);
+        in_r[r][0] = vr.x; in_r[r][1] = vr.y; in_r[r][2] = vr.z; in_r[r][3] = vr.w;
+        in_i[r][0] = vi.x; in_i[r][1] = vi.y; in_i[r][2] = vi.z; in_i[r][3] = vi.w;
+      }
+      uint32_t o_r[R][4], o_i[R][4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {        // two samples (one dword of each plane) at a time
+        float ur[2][R], ui[2][R];
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) {
+          stockham::cf v[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const h2 hr = __builtin_bit_cast(h2, in_r[r][e2]), hi = __builtin_bit_cast(h2, in_i[r][e2]);
+            v[r] = stockham::cf{static_cast<float>(hr[lo]), static_cast<float>(hi[lo])};
+          }
+          stockham::dft<R>(v);
+          // u_s = v[s] w_N^(s m) / (2 R): powers of w1 = w_N^m
+          float pw_re = w1_re, pw_im = w1_im;
+          ur[lo][0] = v[0].re * (0.5f / R);
+          ui[lo][0] = v[0].im * (0.5f / R);
+#pragma unroll
+          for (int s2 = 1; s2 < R; ++s2) {
+            const float xr = v[s2].re * (0.5f / R), xi = v[s2].im * (0.5f / R);
+            ur[lo][s2] = __builtin_fmaf(xr, pw_re, -(xi * pw_im));
+            ui[lo][s2] = __builtin_fmaf(xr, pw_im, xi * pw_re);
+            if (s2 + 1 < R) {
+              const float nr = __builtin_fmaf(pw_re, w1_re, -(pw_im * w1_im));
+              const float ni = __builtin_fmaf(pw_re, w1_im, pw_im * w1_re);
+              pw_re = nr;
+              pw_im = ni;
+            }
+          }
+          // next sample: w_N^(m + 1)
+          const float nr = __builtin_fmaf(w1_re, st_re, -(w1_im * st_im));
+          const float ni = __builtin_fmaf(w1_re, st_im, w1_im * st_re);
+          w1_re = nr;
+          w1_im = ni;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < R; ++s2) {
+          o_r[s2][e2] = pk(ur[0][s2], ur[1][s2]);
+          o_i[s2][e2] = pk(ui[0][s2], ui[1][s2]);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < R; ++s2) {
+        *reinterpret_cast<u4*>(gl + s2 * kLdsWaveBytes + slot) = u4{o_r[s2][0], o_r[s2][1], o_r[s2][2], o_r[s2][3]};
+        *reinterpret_cast<u4*>(gl + s2 * kLdsWaveBytes + 8192 + slot) = u4{o_i[s2][0], o_i[s2][1], o_i[s2][2], o_i[s2][3]};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // B: u_0 .. u_(R-1) are complete
+
+    // ---- stage 1 on this wave's own region, exactly the 4096 kernel's: D1_n1[k0 = 4g + r][n0 = lane & 15]
     uint32_t pr[8][4], pi[8][4];
-    float q_re = 1.f, q_im = 0.f;            // w_N^(16 s n1)
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       f4 dre[2], dim[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int n1 = 2 * t + e;
-        float a_re[4] = {0.f, 0.f, 0.f, 0.f}, a_im[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const uint8_t* ad = tr_base + r * kLdsWaveBytes + 32 * (n1 ^ mrow);
-          const s4 xr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad));
-          const s4 xi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad + 8192));
-          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-          const h4 hr = __builtin_bit_cast(h4, xr), hi = __builtin_bit_cast(h4, xi);
-          if constexpr (R == 2) {        // w_2^(r s) = +-1: two multiply-adds per sample
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              a_re[j] = __builtin_fmaf(static_cast<float>(hr[j]), c_re[r], a_re[j]);
-              a_im[j] = __builtin_fmaf(static_cast<float>(hi[j]), c_re[r], a_im[j]);
-            }
-          } else {
-            // general complex multiply-add, also for the +-1 / +-i roots: choosing the cheaper form per (r, s) needs
-            // wave-uniform branches inside this loop, which cost far more than they save (2^14: 415 -> 339
-            // Gsamples/s, 2^15: 340 -> 247 when tried)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float vr = static_cast<float>(hr[j]), vi = static_cast<float>(hi[j]);
-              a_re[j] = __builtin_fmaf(vr, c_re[r], __builtin_fmaf(-vi, c_im[r], a_re[j]));
-              a_im[j] = __builtin_fmaf(vr, c_im[r], __builtin_fmaf(vi, c_re[r], a_im[j]));
-            }
-          }
-        }
-        float u_re[4], u_im[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float w_re = __builtin_fmaf(pt_re[j], q_re, -(pt_im[j] * q_im));
-          const float w_im = __builtin_fmaf(pt_re[j], q_im, pt_im[j] * q_re);
-          u_re[j] = __builtin_fmaf(a_re[j], w_re, -(a_im[j] * w_im));
-          u_im[j] = __builtin_fmaf(a_re[j], w_im, a_im[j] * w_re);
-        }
-        const u4 raw = {pk(u_re[0], u_re[1]), pk(u_re[2], u_re[3]), pk(u_im[0], u_im[1]), pk(u_im[2], u_im[3])};
+        const uint8_t* ad = tr_base + 32 * (n1 ^ mrow);
+        const s4 xr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad));
+        const s4 xi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(ad + 8192));
+        const u4 raw = {__builtin_bit_cast(u2, xr).x, __builtin_bit_cast(u2, xr).y,
+                        __builtin_bit_cast(u2, xi).x, __builtin_bit_cast(u2, xi).y};
         const h8 xop = __builtin_bit_cast(h8, raw);
         dre[e] = mfma(f_re, xop);
         dim[e] = mfma(f_im, xop);
-        const float nq_re = __builtin_fmaf(q_re, qs_re, -(q_im * qs_im));
-        const float nq_im = __builtin_fmaf(q_re, qs_im, q_im * qs_re);
-        q_re = nq_re;
-        q_im = nq_im;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pr[t][r] = pk(dre[0][r], dre[1][r]);
         pi[t][r] = pk(dim[0][r], dim[1][r]);
       }
-      // keep the scheduler from hoisting every tile's 2 R transposed reads to the top of the loop (it did: 256 VGPRs
-      // and scratch spills); one tile pair in flight is enough with two waves per SIMD
-      asm volatile("" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // B: the input images have been consumed by every wave
+    // (the transposed reads above have returned before the staging stores below are issued: their data feeds the
+    // MFMAs whose results those stores depend on; the region is private to this wave from here to barrier C)
 
     // ---- n1 high bits (register index) <-> k0 high bits (lane group), as in the 4096 kernel
 #pragma unroll
