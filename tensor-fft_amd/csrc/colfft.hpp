@@ -58,6 +58,11 @@ struct Args {
   double inv_t;                     // 1 / T
   uint64_t n_mask;                  // N - 1
   uint32_t copy_only;               // timing experiment (WRONG output): move the image straight back out
+  // radix-512 columns-in-registers pass as the second pass of a 2D transform (see k4096r.hpp, ROWS): output row k of
+  // batch entry e goes to (e >> out_sub_shift) * out_stride + (e & mask) * out_sub_stride + (k << out_row_shift) rows
+  uint32_t out_row_shift;
+  uint32_t out_sub_shift;
+  uint64_t out_sub_stride;
   const float2* tw_lo;
   const float2* tw_hi;
   const uint8_t* tables;            // k4096::build_tables blob
@@ -867,8 +872,11 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     }
 
     // ---- radix-2 combine at read-out: this thread takes 16-byte chunks (8 columns) of rows k and k + 256
-    uint16_t* const o_re = a.out_re + bidx * a.out_stride;
-    uint16_t* const o_im = a.out_im + bidx * a.out_stride;
+    const uint64_t o_entry = (bidx >> a.out_sub_shift) * a.out_stride +
+                             (bidx & ((1ull << a.out_sub_shift) - 1)) * a.out_sub_stride;
+    uint16_t* const o_re = a.out_re + o_entry;
+    uint16_t* const o_im = a.out_im + o_entry;
+    const uint32_t row_shift = a.ns_f_shift + a.out_row_shift;
     const uint64_t restb = mb >> a.ns_f_shift;                 // shared by the block's 64 columns (ns_f % 64 == 0)
     const uint64_t obase = ((restb << 9) << a.ns_f_shift) + (mb - (restb << a.ns_f_shift));
     cpx w_av = {1.f, 0.f}, w_half = {1.f, 0.f};
@@ -920,8 +928,8 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       const u4 s0i = {pk(x0i[0], x0i[1]), pk(x0i[2], x0i[3]), pk(x0i[4], x0i[5]), pk(x0i[6], x0i[7])};
       const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
       const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
-      const uint64_t o0 = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
-      const uint64_t o1 = o0 + (static_cast<uint64_t>(256) << a.ns_f_shift);
+      const uint64_t o0 = obase + (static_cast<uint64_t>(k) << row_shift) + 8 * chunk;
+      const uint64_t o1 = o0 + (static_cast<uint64_t>(256) << row_shift);
       __builtin_nontemporal_store(s0r, reinterpret_cast<u4*>(o_re + o0));
       __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(o_im + o0));
       __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(o_re + o1));

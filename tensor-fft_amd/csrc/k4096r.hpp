@@ -30,7 +30,16 @@ using namespace k4096;
 
 // (Tried: two independent 4-wave workgroups per CU with the G table read from global memory instead of LDS, so that one
 // workgroup computes while the other waits for memory: 2^13 487 -> 456 Gsamples/s, 2^14 435 -> 445; not kept.)
-template <int R>
+//
+// ROWS (R = 8 only): the same machinery as the FIRST pass of a 2D transform of 4096 x 4096 images (include/tfft.h,
+// tfft_plan2d_*). The column transform of length 4096 = 8 x 512 is split decimation-in-frequency, r = r0 + 512 i:
+//   Y_s[r0][c] = w_4096^(r0 s) / 16  sum_i x[r0 + 512 i][c] w_8^(i s),     X[8 k' + s][kc] = DFT_512 over r0 of rowDFT(Y_s[r0])[kc]
+// One workgroup iteration takes the 8 rows r0 + 512 i of an image (wave i copies row i), does the radix-8 butterfly in
+// place across the 8 regions (the twiddle is one scalar per s), runs the 4096-point ROW transform of Y_s in wave s and
+// stores it as row 512 s + r0 of the intermediate image. What remains is a radix-512 column pass over each block of
+// 512 rows (colfft512_wg_kernel) that writes rows 8 k' + s: two passes over HBM instead of three. `batch` then counts
+// workgroup iterations (images x 512) and the strides are per image.
+template <int R, bool ROWS = false>
 __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                                uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
                                                                uint64_t out_stride, uint32_t batch,
@@ -69,14 +78,17 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
 
   const uint32_t out_chunk = 4096u * s;     // this wave stores halves [4096 s, 4096 (s + 1)) of each output plane
 
-  const uint32_t groups_total = (batch + kGroups - 1) / kGroups;
+  static_assert(!ROWS || R == 8, "the 2D row form takes the 8 rows r0 + 512 i of an image");
+  const uint32_t groups_total = ROWS ? batch : (batch + kGroups - 1) / kGroups;
   for (uint32_t it = blockIdx.x; it < groups_total; it += gridDim.x) {
     // a group past the end of the batch re-does the last transform (it keeps the barriers uniform) without storing
-    const uint32_t b_raw = it * kGroups + grp;
-    const bool live = b_raw < batch;
+    const uint32_t b_raw = ROWS ? (it >> 9) : it * kGroups + grp;      // ROWS: image index; r0 = it & 511
+    const bool live = ROWS || b_raw < batch;
     const uint32_t b = live ? b_raw : batch - 1;
-    dma_in<true>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(b) * in_stride + 4096 * s),
-                 reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(b) * in_stride + 4096 * s), wl_off, lane);
+    const uint32_t r0 = it & 511;
+    const uint64_t in_off = ROWS ? static_cast<uint64_t>(r0 + 512 * s) * 4096 : 4096ull * s;
+    dma_in<true>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(b) * in_stride + in_off),
+                 reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(b) * in_stride + in_off), wl_off, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // A: all R blocks of every group's transform are in LDS
 
@@ -87,8 +99,9 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     for (int ps = 0; ps < 8 / R; ++ps) {
       const int mm = s * (8 / R) + ps;                               // 1-KiB block of the plane: chunks 64 mm .. 64 mm + 63
       const uint32_t slot = mm * 1024 + 16 * (lane ^ (2 * mm));      // LDS slot of global chunk c = 64 mm + lane
-      const float rev0 = static_cast<float>(8 * (64 * mm + lane)) * (1.0f / kN);   // m0 / N, exact
-      float w1_re = __builtin_amdgcn_cosf(rev0), w1_im = -__builtin_amdgcn_sinf(rev0);   // w_N^m, m = m0 + e
+      // w_N^m, m = m0 + e (1D) or the per-iteration scalar w_4096^r0 (2D rows)
+      const float rev0 = ROWS ? static_cast<float>(r0) * (1.0f / 4096) : static_cast<float>(8 * (64 * mm + lane)) * (1.0f / kN);
+      float w1_re = __builtin_amdgcn_cosf(rev0), w1_im = -__builtin_amdgcn_sinf(rev0);
       // (plain dword arrays: __builtin_bit_cast applied directly to an element of an ext-vector reads element 0)
       uint32_t in_r[R][4], in_i[R][4];
 #pragma unroll
@@ -127,11 +140,12 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
               pw_im = ni;
             }
           }
-          // next sample: w_N^(m + 1)
-          const float nr = __builtin_fmaf(w1_re, st_re, -(w1_im * st_im));
-          const float ni = __builtin_fmaf(w1_re, st_im, w1_im * st_re);
-          w1_re = nr;
-          w1_im = ni;
+          if (!ROWS) {        // next sample: w_N^(m + 1)
+            const float nr = __builtin_fmaf(w1_re, st_re, -(w1_im * st_im));
+            const float ni = __builtin_fmaf(w1_re, st_im, w1_im * st_re);
+            w1_re = nr;
+            w1_im = ni;
+          }
         }
 #pragma unroll
         for (int s2 = 0; s2 < R; ++s2) {
@@ -225,6 +239,21 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         *reinterpret_cast<u4*>(wl + off) = u4{ore[r2][0], ore[r2][1], ore[r2][2], ore[r2][3]};
         *reinterpret_cast<u4*>(wl + 8192 + off) = u4{oim[r2][0], oim[r2][1], oim[r2][2], oim[r2][3]};
       }
+    }
+    if (ROWS) {
+      // the row spectrum leaves from this wave's own region (no other wave needs it): row 512 s + r0 of the image
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      uint16_t* const row_re = out_re + static_cast<uint64_t>(b) * out_stride + static_cast<uint64_t>(512 * s + r0) * 4096;
+      uint16_t* const row_im = out_im + static_cast<uint64_t>(b) * out_stride + static_cast<uint64_t>(512 * s + r0) * 4096;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u4 vr = *reinterpret_cast<const u4*>(wl + 1024 * i + 16 * lane);
+        const u4 vi = *reinterpret_cast<const u4*>(wl + 8192 + 1024 * i + 16 * lane);
+        __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(row_re + 512 * i + 8 * lane));
+        __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(row_im + 512 * i + 8 * lane));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read out before this wave's next copy-in lands on the region
+      continue;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // C: the R spectra of every group are staged

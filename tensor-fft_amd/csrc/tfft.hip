@@ -68,6 +68,9 @@ struct tfft_plan {
   bool preserve_input = false;
   int num_cus = 0;
   int variant = 0;
+  // output re-mapping of a single radix-512 column pass (second pass of the fused 2D plan, see tfft_plan2d_create)
+  uint32_t out_row_shift = 0, out_sub_shift = 0;
+  uint64_t out_sub_stride = 0;
   std::vector<Pass> passes;
   void* d_tables = nullptr;     // k4096::build_tables blob (K4096 and Col256 passes)
   float2* d_tw_lo = nullptr;    // w_n tables (Col256 and Stockham passes)
@@ -214,6 +217,25 @@ int launch_k4096r(const tfft_plan* p, int radix, const void* in_re, const void* 
   }
 }
 
+// first pass of the fused 2D plan: iterations = images * 512 (k4096r.hpp, ROWS); p only lends its device and tables
+int launch_rows2d(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                  uint64_t image_stride, uint32_t iterations, hipStream_t s) {
+  static std::once_flag once[16];
+  hipError_t attr = hipSuccess;
+  std::call_once(once[p->device & 15], [&] {
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k4096r::fft4096r_kernel<8, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, k4096::kLdsBytes);
+  });
+  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+  const uint32_t grid = std::min<uint32_t>(iterations, static_cast<uint32_t>(p->num_cus));
+  hipLaunchKernelGGL((k4096r::fft4096r_kernel<8, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+                     static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), image_stride, image_stride,
+                     iterations, static_cast<const uint8_t*>(p->d_tables));
+  TFFT_HIP(hipGetLastError());
+  return TFFT_OK;
+}
+
 int launch_k4096(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                  uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
   // opts.variant: 0 = default (staged, coalesced, non-temporal stores: the fastest measured on MI355X);
@@ -313,6 +335,9 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   a.tables = static_cast<const uint8_t*>(p->d_tables);
   a.n_mask = p->n - 1;
   a.copy_only = (p->variant & 65536) ? 1u : 0u;
+  a.out_row_shift = p->out_row_shift;
+  a.out_sub_shift = p->out_sub_shift;
+  a.out_sub_stride = p->out_sub_stride;
   a.a_shift = 0;
   a.t_mask = 0;
   a.n_over_t = 1;
@@ -695,6 +720,12 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
       radices.insert(radices.end(), best_b, 512);
       rem = lg - 8 * best_a - 9 * best_b;
     }
+    // n = 512 along a strided axis as ONE radix-512 column pass (variant bit 67108864; the second pass of the fused 2D plan)
+    if (n == 512 && inner >= 64 && (opts && (opts->variant & 67108864)) && !force_stockham) {
+      radices.assign(1, 512);
+      n256 = 1;
+      rem = 0;
+    }
     for (; rem >= 4; rem -= 4) radices.push_back(16);
     if (rem) radices.push_back(1 << rem);
     // a radix-16 pass followed by a radix-2 / radix-4 pass behind a column pass fuses into one radix-32 / radix-64
@@ -815,6 +846,7 @@ struct tfft_plan2d {
   tfft_plan* col = nullptr;
   uint64_t rows = 0, cols = 0, batch = 0;
   int device = 0;
+  bool fused = false;       // 4096 x 4096: radix-8 column butterfly fused into the row pass + one radix-512 column pass
   mutable std::mutex ws_mutex;
   mutable void* ws = nullptr;
   mutable size_t ws_bytes = 0;
@@ -832,17 +864,40 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
   p->cols = cols;
   p->batch = batch;
   p->device = device_id;
-  tfft_plan_opts ro{};
-  ro.in_batch_stride = cols;        // fully planar lines
-  ro.out_batch_stride = cols;
-  ro.preserve_input = 1;
-  int rc = tfft_plan_create(cols, batch * rows, device_id, &ro, &p->row);
-  if (rc == TFFT_OK) {
-    tfft_plan_opts co{};
-    co.in_batch_stride = rows * cols;
-    co.out_batch_stride = rows * cols;
-    co.inner = cols;
-    rc = tfft_plan_create(rows, batch, device_id, &co, &p->col);
+  static const bool no_fuse = std::getenv("TFFT_2D_NO_FUSE") != nullptr;   // experiment knob
+  p->fused = (rows == 4096 && cols == 4096 && batch * 512 <= 0xffffffffull && !no_fuse);
+  int rc;
+  if (p->fused) {
+    // pass 1 (k4096r.hpp, ROWS): radix-8 column butterfly over the rows r0 + 512 i, fused with the 4096-point row
+    // transforms; it only needs the 4096 kernel's constant tables, which a (4096, 1) plan owns.
+    rc = tfft_plan_create(4096, 1, device_id, nullptr, &p->row);
+    if (rc == TFFT_OK) {
+      // pass 2: one radix-512 column pass per block of 512 intermediate rows; block s of an image writes rows 8 k' + s
+      tfft_plan_opts co{};
+      co.in_batch_stride = 512 * cols;
+      co.out_batch_stride = rows * cols;
+      co.inner = cols;
+      co.variant = 67108864;
+      rc = tfft_plan_create(512, batch * 8, device_id, &co, &p->col);
+      if (rc == TFFT_OK) {
+        p->col->out_row_shift = 3;
+        p->col->out_sub_shift = 3;
+        p->col->out_sub_stride = cols;
+      }
+    }
+  } else {
+    tfft_plan_opts ro{};
+    ro.in_batch_stride = cols;        // fully planar lines
+    ro.out_batch_stride = cols;
+    ro.preserve_input = 1;
+    rc = tfft_plan_create(cols, batch * rows, device_id, &ro, &p->row);
+    if (rc == TFFT_OK) {
+      tfft_plan_opts co{};
+      co.in_batch_stride = rows * cols;
+      co.out_batch_stride = rows * cols;
+      co.inner = cols;
+      rc = tfft_plan_create(rows, batch, device_id, &co, &p->col);
+    }
   }
   if (rc != TFFT_OK) {
     const std::string keep = g_err;
@@ -863,7 +918,8 @@ void tfft_plan2d_destroy(tfft_plan2d* p) {
 }
 
 int tfft_plan2d_num_launches(const tfft_plan2d* p) {
-  return p ? tfft_plan_num_launches(p->row) + tfft_plan_num_launches(p->col) : 0;
+  if (!p) return 0;
+  return (p->fused ? 1 : tfft_plan_num_launches(p->row)) + tfft_plan_num_launches(p->col);
 }
 
 namespace {
@@ -873,6 +929,7 @@ inline size_t plan2d_part(size_t bytes) { return (bytes + 255) & ~static_cast<si
 
 size_t tfft_plan2d_workspace_bytes(const tfft_plan2d* p) {
   if (!p) return 0;
+  if (p->fused) return plan2d_part(plan2d_tmp_bytes(p));          // the intermediate image set only
   return plan2d_part(plan2d_tmp_bytes(p)) + plan2d_part(tfft_plan_workspace_bytes(p->row)) +
          tfft_plan_workspace_bytes(p->col);
 }
@@ -908,17 +965,29 @@ int tfft_plan2d_exec(const tfft_plan2d* p, const void* in_re, const void* in_im,
       p->ws_bytes = need;
       p->ws_owned = true;
     }
-    uint8_t* base = static_cast<uint8_t*>(p->ws);
-    const size_t tmp = plan2d_part(plan2d_tmp_bytes(p)), row_ws = plan2d_part(tfft_plan_workspace_bytes(p->row));
-    int rc = tfft_plan_set_workspace(p->row, row_ws ? base + tmp : nullptr, row_ws);
-    if (rc == TFFT_OK) {
-      const size_t col_ws = tfft_plan_workspace_bytes(p->col);
-      rc = tfft_plan_set_workspace(p->col, col_ws ? base + tmp + row_ws : nullptr, col_ws);
+    if (!p->fused) {
+      uint8_t* base = static_cast<uint8_t*>(p->ws);
+      const size_t tmp = plan2d_part(plan2d_tmp_bytes(p)), row_ws = plan2d_part(tfft_plan_workspace_bytes(p->row));
+      int rc = tfft_plan_set_workspace(p->row, row_ws ? base + tmp : nullptr, row_ws);
+      if (rc == TFFT_OK) {
+        const size_t col_ws = tfft_plan_workspace_bytes(p->col);
+        rc = tfft_plan_set_workspace(p->col, col_ws ? base + tmp + row_ws : nullptr, col_ws);
+      }
+      if (rc != TFFT_OK) return rc;
     }
-    if (rc != TFFT_OK) return rc;
   }
   _Float16* t_re = static_cast<_Float16*>(p->ws);
   _Float16* t_im = t_re + static_cast<size_t>(p->batch) * p->rows * p->cols;
+  if (p->fused) {
+    if (!in_re || !in_im || !out_re || !out_im) return fail(TFFT_ERR_ARG, "null data pointer");
+    int cur = 0;
+    TFFT_HIP(hipGetDevice(&cur));
+    if (cur != p->device) return fail(TFFT_ERR_ARG, "plan was created for another device than the current one");
+    const int rc = launch_rows2d(p->row, in_re, in_im, t_re, t_im, p->rows * p->cols, static_cast<uint32_t>(p->batch * 512),
+                                 static_cast<hipStream_t>(stream));
+    if (rc != TFFT_OK) return rc;
+    return tfft_exec(p->col, t_re, t_im, out_re, out_im, stream);
+  }
   int rc = tfft_exec(p->row, in_re, in_im, t_re, t_im, stream);
   if (rc != TFFT_OK) return rc;
   return tfft_exec(p->col, t_re, t_im, out_re, out_im, stream);

@@ -457,6 +457,20 @@ def test_2d_4096_square_properties(tf, torch):
     e_in = float((re[2].float() ** 2 + im[2].float() ** 2).sum()) / (n * n)
     e_out = float((o_re[2].float() ** 2 + o_im[2].float() ** 2).sum())
     assert abs(e_out - e_in) / e_in < 5e-3
+    # the random image against hipFFT (complex64) on the same fp16 input; this shape runs the fused two-pass plan
+    assert plan.num_launches == 2
+    want = torch.fft.fft2(torch.complex(re[2].float(), im[2].float())) / (n * n)
+    got = torch.complex(o_re[2].float(), o_im[2].float())
+    assert float(torch.linalg.vector_norm(got - want) / torch.linalg.vector_norm(want)) <= REL_L2_TOL
+    # a full-scale image stays finite (headroom of the fused radix-8 butterfly)
+    re[0] = (torch.rand(n, n, device="cuda", generator=gen) * 2 - 1).half() * 65504
+    im[0] = (torch.rand(n, n, device="cuda", generator=gen) * 2 - 1).half() * 65504
+    plan.exec(re.reshape(-1), im.reshape(-1), o_re.reshape(-1), o_im.reshape(-1))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o_re[0]).all()) and bool(torch.isfinite(o_im[0]).all())
+    want = torch.fft.fft2(torch.complex(re[0].float(), im[0].float())) / (n * n)
+    got = torch.complex(o_re[0].float(), o_im[0].float())
+    assert float(torch.linalg.vector_norm(got - want) / torch.linalg.vector_norm(want)) <= REL_L2_TOL
 
 
 def test_n_2pow20(tf, torch, orc):
