@@ -574,14 +574,16 @@ def test_layout_adapters_roundtrip(tf, torch):
     assert float((got - want).abs().pow(2).sum().sqrt() / want.abs().pow(2).sum().sqrt()) < REL_L2_TOL
 
 
-def test_exec_is_graph_capturable(tf, torch):
-    """tfft_exec allocates nothing once the workspace is set, so a pass chain can be captured in a HIP graph."""
-    n, batch = 1 << 16, 8
+@pytest.mark.parametrize("n,batch", [(1 << 16, 8), (1 << 13, 6), (1 << 17, 4), (1 << 21, 1)])
+def test_exec_is_graph_capturable(tf, torch, n, batch):
+    """tfft_exec allocates nothing once the workspace is set, so a pass chain can be captured in a HIP graph
+    (column passes, the single-pass 8192 kernel, radix-512 passes, fused tails)."""
     x = (torch.rand(batch * 2 * n, device="cuda") * 2 - 1).half()
     y = torch.zeros_like(x)
     plan = tf.TfftPlan(n, batch, 0, preserve_input=True)
-    ws = torch.empty(plan.workspace_bytes // 2, dtype=torch.float16, device="cuda")
-    plan.set_workspace(ws)
+    ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+    if plan.workspace_bytes:
+        plan.set_workspace(ws)
     plan.exec(x, x[n:], y, y[n:])                     # warm-up (sets function attributes)
     torch.cuda.synchronize()
     ref = y.clone()
@@ -595,6 +597,27 @@ def test_exec_is_graph_capturable(tf, torch):
     graph.replay()
     torch.cuda.synchronize()
     assert bool((y == ref).all())
+
+
+def test_2d_plan_is_graph_capturable(tf, torch):
+    n, batch = 4096, 2
+    re = (torch.rand(batch * n * n, device="cuda") * 2 - 1).half()
+    im = (torch.rand(batch * n * n, device="cuda") * 2 - 1).half()
+    o_re, o_im = torch.zeros_like(re), torch.zeros_like(im)
+    plan = tf.TfftPlan2D(n, n, batch, 0)
+    plan.exec(re, im, o_re, o_im)                     # warm-up: workspace, function attributes
+    torch.cuda.synchronize()
+    ref_re, ref_im = o_re.clone(), o_im.clone()
+    o_re.zero_(); o_im.zero_()
+    s = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            plan.exec(re, im, o_re, o_im, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert bool((o_re == ref_re).all()) and bool((o_im == ref_im).all())
 
 
 def test_argument_errors(tf, torch):
