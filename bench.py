@@ -210,6 +210,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kernel_ms = float(t[0]), float(t[1])
 
+    # per-launch spread (SURVEY 8d asks for mean and sigma; the true mean, not the reference's sum / (n - 1),
+    # BenchUtil.h:41-48): 20 individually timed launches after the timed region, not part of `value`
+    singles = []
+    for _ in range(20):
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        step()
+        a1.record()
+        torch.cuda.synchronize()
+        singles.append(a0.elapsed_time(a1))
+    single_mean = sum(singles) / len(singles)
+    single_sigma = (sum((v - single_mean) ** 2 for v in singles) / (len(singles) - 1)) ** 0.5
+
     # light self-check so a broken kernel cannot post a number: Parseval on a slice
     xs = x[: 64 * 2 * N].float().reshape(64, 2 * N)
     ys = y[: 64 * 2 * N].float().reshape(64, 2 * N)
@@ -255,6 +268,7 @@ def main():
                 "traffic": traffic[0] if traffic else None,
                 "traffic_source": traffic[1] if traffic else None,
                 "kernel_ms": kernel_ms,
+                "kernel_ms_single_launches": {"mean": single_mean, "sigma": single_sigma, "n": len(singles)},
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
             "mfma": {"tflops": mfma_tflops, "peak": MFMA_PEAK_TFLOPS, "frac": mfma_tflops / MFMA_PEAK_TFLOPS,
