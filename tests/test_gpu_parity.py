@@ -704,3 +704,48 @@ def test_against_vendor_fft_on_device(tf, torch, lg):
     rel = float(torch.linalg.vector_norm(got - want) / torch.linalg.vector_norm(want))
     assert rel <= REL_L2_TOL, rel
     assert float((got - want).abs().max()) <= 8 * 2.0 ** -11 * float(want.abs().max())
+
+
+def test_randomized_plan_space(tf, torch):
+    """60 random points of the plan space (length 2 .. 2^19, batch, padded / planar strides, preserve_input, in place)
+    against numpy's fp64 FFT: every kernel family and launch split gets exercised with shapes nobody hand-picked."""
+    rng = np.random.default_rng(20261004)
+    for case in range(60):
+        lg = int(rng.integers(1, 20))
+        n = 1 << lg
+        batch = int(rng.integers(1, max(2, min(48, (1 << 21) // n))))
+        planar = bool(rng.integers(0, 2)) and n >= 8
+        pad = int(rng.integers(0, 3)) * 8 if n >= 8 else 0
+        in_place = bool(rng.integers(0, 2)) and not planar and pad == 0
+        preserve = bool(rng.integers(0, 2)) and not in_place
+        re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+        im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+        exact = np.fft.fft(_c(re, im), axis=1) / n
+        if planar:                      # all RE planes, then all IM planes, each with its own batch stride
+            stride = n + pad
+            d_re = torch.zeros(batch, stride, dtype=torch.float16, device="cuda"); d_re[:, :n] = torch.from_numpy(re).cuda()
+            d_im = torch.zeros(batch, stride, dtype=torch.float16, device="cuda"); d_im[:, :n] = torch.from_numpy(im).cuda()
+            o_re, o_im = torch.zeros_like(d_re), torch.zeros_like(d_im)
+            plan = tf.TfftPlan(n, batch, 0, in_batch_stride=stride, out_batch_stride=stride, preserve_input=preserve)
+            keep = d_re.clone()
+            plan.exec(d_re.reshape(-1), d_im.reshape(-1), o_re.reshape(-1), o_im.reshape(-1))
+            torch.cuda.synchronize()
+            got = _c(o_re[:, :n].cpu().numpy(), o_im[:, :n].cpu().numpy())
+            if preserve:
+                assert bool((d_re == keep).all()), (case, n, batch)
+        else:                           # [fft RE | fft IM] blocks, optionally padded
+            stride = 2 * n + pad
+            blk = torch.zeros(batch, stride, dtype=torch.float16, device="cuda")
+            blk[:, :n] = torch.from_numpy(re).cuda(); blk[:, n:2 * n] = torch.from_numpy(im).cuda()
+            out = blk if in_place else torch.zeros_like(blk)
+            plan = tf.TfftPlan(n, batch, 0, in_batch_stride=stride, out_batch_stride=stride, preserve_input=preserve)
+            keep = blk.clone()
+            flat_in, flat_out = blk.reshape(-1), out.reshape(-1)
+            plan.exec(flat_in, flat_in[n:], flat_out, flat_out[n:])
+            torch.cuda.synchronize()
+            got = _c(out[:, :n].cpu().numpy(), out[:, n:2 * n].cpu().numpy())
+            if preserve:
+                assert bool((blk == keep).all()), (case, n, batch)
+        rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+        assert np.isfinite(got).all() and rel <= REL_L2_TOL, (case, n, batch, planar, pad, in_place, preserve, rel)
+
