@@ -749,3 +749,40 @@ def test_randomized_plan_space(tf, torch):
         rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
         assert np.isfinite(got).all() and rel <= REL_L2_TOL, (case, n, batch, planar, pad, in_place, preserve, rel)
 
+
+def test_randomized_strided_axis_and_2d(tf, torch):
+    """Random transforms along a strided axis (data [batch][n][C]) and random 2D shapes against numpy."""
+    rng = np.random.default_rng(4242)
+    for case in range(30):
+        lg = int(rng.integers(1, 14))
+        n = 1 << lg
+        inner = int(2 ** rng.integers(3, 11))
+        batch = int(rng.integers(1, 4))
+        if n * inner * batch > (1 << 23):
+            continue
+        re = rng.uniform(-1, 1, (batch, n, inner)).astype(np.float16)
+        im = rng.uniform(-1, 1, (batch, n, inner)).astype(np.float16)
+        host = np.ascontiguousarray(np.stack([re, im], axis=1))           # [batch][RE | IM][n][C]
+        dev = torch.from_numpy(host).cuda().reshape(-1)
+        out = torch.zeros_like(dev)
+        tf.TfftPlan(n, batch, 0, inner=inner).exec(dev, dev[n * inner:], out, out[n * inner:])
+        torch.cuda.synchronize()
+        o = out.cpu().numpy().reshape(batch, 2, n, inner)
+        got = _c(o[:, 0], o[:, 1])
+        exact = np.fft.fft(_c(re, im), axis=1) / n
+        rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+        assert np.isfinite(got).all() and rel <= REL_L2_TOL, (case, n, inner, batch, rel)
+    for case in range(8):
+        rows, cols = int(2 ** rng.integers(1, 11)), int(2 ** rng.integers(3, 12))
+        batch = int(rng.integers(1, 4))
+        re = rng.uniform(-1, 1, (batch, rows, cols)).astype(np.float16)
+        im = rng.uniform(-1, 1, (batch, rows, cols)).astype(np.float16)
+        d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
+        o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
+        tf.TfftPlan2D(rows, cols, batch, 0).exec(d_re, d_im, o_re, o_im)
+        torch.cuda.synchronize()
+        got = _c(o_re.cpu().numpy(), o_im.cpu().numpy()).reshape(batch, rows, cols)
+        exact = np.fft.fft2(_c(re, im), axes=(1, 2)) / (rows * cols)
+        rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+        assert rel <= REL_L2_TOL, (case, rows, cols, batch, rel)
+
