@@ -201,6 +201,21 @@ def test_full_scale_inputs_do_not_overflow(tf, torch, orc, n):
     assert np.linalg.norm(got[2] - exact[0]) / np.linalg.norm(exact[0]) < REL_L2_TOL
 
 
+@pytest.mark.parametrize("n", [256, 512, 2048, 8192, 32768, 65536])
+def test_tiny_magnitudes(tf, torch, orc, n):
+    """Inputs of amplitude 2e-3: outputs land in binary16's subnormal range (quantum 6e-8); no stage may flush them
+    (the reference's up-front x / N does: TensorFFT4096.cu:169-173). Absolute bound: two subnormal quanta + 1e-3 relative."""
+    rng = np.random.default_rng(n + 5)
+    re = (rng.uniform(-1, 1, (2, n)) * 2e-3).astype(np.float16)
+    im = (rng.uniform(-1, 1, (2, n)) * 2e-3).astype(np.float16)
+    gr, gi = _run(tf, torch, re, im)
+    exact = _c(*orc.dft64(re, im))
+    got = _c(gr, gi)
+    assert np.isfinite(got).all()
+    assert np.abs(got - exact).max() < 2 * 2.0 ** -24 + 1e-3 * np.abs(exact).max()
+    assert np.linalg.norm(got) > 0.5 * np.linalg.norm(exact)          # not flushed to zero
+
+
 def test_n4096_in_place_and_strides(tf, torch, orc):
     n, batch = 4096, 19
     rng = np.random.default_rng(21)
