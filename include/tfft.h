@@ -155,6 +155,9 @@ size_t tfft_plan2d_workspace_bytes(const tfft_plan2d* plan);
 int tfft_plan2d_set_workspace(tfft_plan2d* plan, void* device_ptr, size_t bytes);
 int tfft_plan2d_exec(const tfft_plan2d* plan, const void* in_re, const void* in_im, void* out_re, void* out_im,
                      void* stream);
+/* inverse 2D transform (planes exchanged on both sides, as tfft_exec_inverse) */
+int tfft_plan2d_exec_inverse(const tfft_plan2d* plan, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                             void* stream);
 
 /* out[b][a][c] = in[a][b][c] * w_n_tw^((e0 + b) * (a*C + c)), planar binary16, c contiguous (C % 8 == 0);
  * n_tw == 0: pure re-ordering. The pack / twiddle / unpack step around the single all-to-all of a transform

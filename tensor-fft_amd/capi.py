@@ -18,7 +18,7 @@ SYMBOLS = [
     "tfft_exec", "tfft_plan_kernel_name", "tfft_plan_algorithmic_bytes", "tfft_plan_mfma_flops",
     "tfft_last_error", "tfft_version", "tfft_permute_twiddle", "tfft_exec_inverse", "tfft_deinterleave", "tfft_interleave",
     "tfft_plan2d_create", "tfft_plan2d_destroy", "tfft_plan2d_num_launches", "tfft_plan2d_workspace_bytes",
-    "tfft_plan2d_set_workspace", "tfft_plan2d_exec",
+    "tfft_plan2d_set_workspace", "tfft_plan2d_exec", "tfft_plan2d_exec_inverse",
 ]
 
 
@@ -121,6 +121,8 @@ def load_library():
     L.tfft_plan2d_set_workspace.argtypes = [vp, vp, ctypes.c_size_t]
     L.tfft_plan2d_exec.restype = ci
     L.tfft_plan2d_exec.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.tfft_plan2d_exec_inverse.restype = ci
+    L.tfft_plan2d_exec_inverse.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tfft_plan_kernel_name.restype = ctypes.c_char_p
     L.tfft_plan_kernel_name.argtypes = [vp]
     L.tfft_plan_algorithmic_bytes.restype = ctypes.c_double
@@ -286,6 +288,10 @@ class TfftPlan2D:
         with torch.cuda.device(self.device):
             _check(self._lib.tfft_plan2d_exec(self._h, in_re.data_ptr(), in_im.data_ptr(), out_re.data_ptr(),
                                               out_im.data_ptr(), stream))
+
+    def exec_inverse(self, in_re, in_im, out_re, out_im, stream=None):
+        """(1 / (rows cols)) sum x exp(+2 pi i (...)): the forward plan with the planes exchanged on both sides."""
+        self.exec(in_im, in_re, out_im, out_re, stream)
 
     def close(self):
         if getattr(self, "_h", None):

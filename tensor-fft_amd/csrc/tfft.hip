@@ -993,6 +993,11 @@ int tfft_plan2d_exec(const tfft_plan2d* p, const void* in_re, const void* in_im,
   return tfft_exec(p->col, t_re, t_im, out_re, out_im, stream);
 }
 
+int tfft_plan2d_exec_inverse(const tfft_plan2d* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                             void* stream) {
+  return tfft_plan2d_exec(p, in_im, in_re, out_im, out_re, stream);
+}
+
 int tfft_permute_twiddle(const void* in_re, const void* in_im, void* out_re, void* out_im, uint64_t a, uint64_t b,
                          uint64_t c, uint64_t n_tw, uint64_t e0, void* stream) {
   g_err.clear();

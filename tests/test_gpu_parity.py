@@ -614,6 +614,25 @@ def test_exec_is_graph_capturable(tf, torch, n, batch):
     assert bool((y == ref).all())
 
 
+def test_2d_inverse_round_trip(tf, torch):
+    """inverse(forward(x)) = x / (rows cols): amplitudes chosen so that the round trip stays above the subnormal range."""
+    rows, cols, batch = 256, 512, 2
+    rng = np.random.default_rng(3)
+    re = (rng.uniform(-1, 1, (batch, rows, cols)) * 30000).astype(np.float16)
+    im = (rng.uniform(-1, 1, (batch, rows, cols)) * 30000).astype(np.float16)
+    d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
+    f_re, f_im = torch.empty_like(d_re), torch.empty_like(d_im)
+    b_re, b_im = torch.empty_like(d_re), torch.empty_like(d_im)
+    plan = tf.TfftPlan2D(rows, cols, batch, 0)
+    plan.exec(d_re, d_im, f_re, f_im)
+    want = np.fft.ifft2(np.fft.fft2(_c(re, im), axes=(1, 2)) / (rows * cols), axes=(1, 2))    # = x / (rows cols)
+    big_re, big_im = (f_re.float() * 256).half(), (f_im.float() * 256).half()                  # keep pass 2 out of the subnormals
+    plan.exec_inverse(big_re, big_im, b_re, b_im)
+    torch.cuda.synchronize()
+    got = _c(b_re.cpu().numpy(), b_im.cpu().numpy()).reshape(batch, rows, cols) / 256
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 3e-3
+
+
 def test_2d_plan_is_graph_capturable(tf, torch):
     n, batch = 4096, 2
     re = (torch.rand(batch * n * n, device="cuda") * 2 - 1).half()
