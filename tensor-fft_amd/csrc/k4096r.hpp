@@ -141,6 +141,9 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
             }
           }
           if (!ROWS) {        // next sample: w_N^(m + 1)
+            // The recurrence does not depend on the data, so the scheduler would run all 8 samples' twiddle powers
+            // ahead (128 live floats for R = 8: 256 VGPRs and spills). Tie it to this sample's result (no instruction).
+            asm volatile("" : "+v"(w1_re), "+v"(w1_im) : "v"(ur[lo][R - 1]));
             const float nr = __builtin_fmaf(w1_re, st_re, -(w1_im * st_im));
             const float ni = __builtin_fmaf(w1_re, st_im, w1_im * st_re);
             w1_re = nr;
