@@ -118,6 +118,11 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
                      tfft_plan** out);
 void tfft_plan_destroy(tfft_plan* plan);
 
+/* Host-only: the pass decomposition tfft_plan_create would choose, as text ("col:256+tw col:512+tw autosort:64-tw",
+ * "k4096:4096", ...: kernel family : radix, "+tw" = applies the next pass's input twiddles, "-tw" = expects them
+ * applied). Touches no device, so the planner is testable without a GPU. */
+int tfft_plan_describe(uint64_t n, uint64_t inner, int variant, char* buf, size_t bytes);
+
 /* Number of passes over the data one tfft_exec makes (= kernel launches, except that a narrow column pass with a
  * ragged batch takes two) and the bytes of device scratch it needs beyond in/out (0 for N <= 32768 with a contiguous axis). If nonzero, either hand memory in
  * with tfft_plan_set_workspace() or let the first tfft_exec hipMalloc it. */

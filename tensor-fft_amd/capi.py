@@ -18,7 +18,7 @@ SYMBOLS = [
     "tfft_exec", "tfft_plan_kernel_name", "tfft_plan_algorithmic_bytes", "tfft_plan_mfma_flops",
     "tfft_last_error", "tfft_version", "tfft_permute_twiddle", "tfft_exec_inverse", "tfft_deinterleave", "tfft_interleave",
     "tfft_plan2d_create", "tfft_plan2d_destroy", "tfft_plan2d_num_launches", "tfft_plan2d_workspace_bytes",
-    "tfft_plan2d_set_workspace", "tfft_plan2d_exec", "tfft_plan2d_exec_inverse",
+    "tfft_plan2d_set_workspace", "tfft_plan2d_exec", "tfft_plan2d_exec_inverse", "tfft_plan_describe",
 ]
 
 
@@ -123,6 +123,8 @@ def load_library():
     L.tfft_plan2d_exec.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tfft_plan2d_exec_inverse.restype = ci
     L.tfft_plan2d_exec_inverse.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.tfft_plan_describe.restype = ci
+    L.tfft_plan_describe.argtypes = [u64, u64, ci, ctypes.c_char_p, ctypes.c_size_t]
     L.tfft_plan_kernel_name.restype = ctypes.c_char_p
     L.tfft_plan_kernel_name.argtypes = [vp]
     L.tfft_plan_algorithmic_bytes.restype = ctypes.c_double
@@ -144,6 +146,13 @@ def last_error():
 def _check(rc):
     if rc != TFFT_OK:
         raise TfftError(rc, last_error())
+
+
+def plan_describe(n, inner=1, variant=0):
+    """tfft_plan_describe: the pass decomposition a plan would get, as text. Host only, no GPU needed."""
+    buf = ctypes.create_string_buffer(256)
+    _check(load_library().tfft_plan_describe(int(n), int(inner), int(variant), buf, len(buf)))
+    return buf.value.decode()
 
 
 def ref_create_plan(fft_length, mode=0, base_fft_warps_per_block=8, r16_warps_per_block=8, r2_blocksize=256):

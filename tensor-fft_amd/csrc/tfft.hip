@@ -90,6 +90,89 @@ inline bool single_kernel(const tfft_plan* p) {
                                    p->passes[0].kind == PassKind::K256R || p->passes[0].kind == PassKind::K4096R);
 }
 
+// Pass decomposition of a plan: pure host logic (no device needed; tfft_plan_describe exposes it to the CPU tests).
+// Single LDS-resident kernels for N = 256 .. 32768 with a contiguous axis; otherwise radix-256 / radix-512 column passes
+// first (they hand the next pass its twiddles), then radix-16 and one radix-2/4/8 autosort pass, a radix-16 + radix-2/4
+// tail fused into radix-32/64. variant bit 32 forces the plain autosort chain.
+void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& passes) {
+  passes.clear();
+  const int lg = ilog2(n);
+  const bool force_stockham = variant & 32;
+  if (n == 4096 && inner == 1 && !force_stockham) {
+    passes.push_back(Pass{PassKind::K4096, 4096, 1, false, false, 0});
+  } else if (n == 256 && inner == 1 && !force_stockham) {
+    passes.push_back(Pass{PassKind::K256, 256, 1, false, false, 0});
+  } else if ((n == 8192 || n == 16384 || n == 32768) && inner == 1 && !force_stockham && !(variant & 16777216)) {
+    // one pass: R waves share a transform, radix-R step in front of the 4096 kernel's stages (variant bit 16777216:
+    // the multi-pass column plan instead)
+    passes.push_back(Pass{PassKind::K4096R, static_cast<int>(n / 4096), 1, false, false, 0});
+  } else if ((n == 512 || n == 1024 || n == 2048) && inner == 1 && !force_stockham) {
+    passes.push_back(Pass{PassKind::K256R, static_cast<int>(n / 256), 1, false, false, 0});
+  } else {
+    int n256 = 0;
+    // radix-256 column passes wherever the geometry allows them
+    const bool col_ok = !force_stockham && (inner == 1 ? lg >= 13 : (lg >= 8 && inner >= 16));
+    if (col_ok) n256 = lg / 8;
+    int rem = lg - 8 * n256;
+    std::vector<int> radices(n256, 256);
+    // Radix-512 column passes where they save a whole pass (2^15 = 512 x 64, 2^17 = 256 x 512, 2^18 = 512 x 512,
+    // 2^23 = 256 x 512 x 64, 2^25, 2^26 = 256 x 512 x 512, 2^27 = 512^3): the split lg = 8 a + 9 b + t, t <= 7, with the
+    // fewest passes (a tail of t bits costs 0 / 1 / 2 passes for t = 0 / 1..6 / 7); ties go to the fewest radix-512
+    // passes (their row segments are 128 bytes, not 256). variant bit 8388608 turns them off.
+    const bool use512 = col_ok && inner == 1 && lg >= 15 && !(variant & 8388608);
+    if (use512) {
+      auto tail_cost = [](int t) { return t == 0 ? 0 : (t <= 6 ? 1 : 2); };
+      int best_a = n256, best_b = 0, best_cost = n256 + tail_cost(rem);
+      for (int b = 1; b <= 3; ++b)
+        for (int a2 = 0; 8 * a2 + 9 * b <= lg; ++a2) {
+          const int t = lg - 8 * a2 - 9 * b;
+          if (t > 7) continue;
+          const int cost = a2 + b + tail_cost(t);
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_a = a2;
+            best_b = b;
+          }
+        }
+      n256 = best_a + best_b;               // column passes in total
+      radices.assign(best_a, 256);
+      radices.insert(radices.end(), best_b, 512);
+      rem = lg - 8 * best_a - 9 * best_b;
+    }
+    // n = 512 along a strided axis as ONE radix-512 column pass (variant bit 67108864; the second pass of the fused 2D plan)
+    if (n == 512 && inner >= 64 && (variant & 67108864) && !force_stockham) {
+      radices.assign(1, 512);
+      n256 = 1;
+      rem = 0;
+    }
+    for (; rem >= 4; rem -= 4) radices.push_back(16);
+    if (rem) radices.push_back(1 << rem);
+    // a radix-16 pass followed by a radix-2 / radix-4 pass behind a column pass fuses into one radix-32 / radix-64
+    // pass (the butterfly fits in registers; its input twiddles come from the column pass). variant bit 2097152 keeps them apart.
+    const bool fuse_tail = !(variant & 2097152);
+    if (fuse_tail && n256 >= 1 && radices.size() >= static_cast<size_t>(n256) + 2) {
+      const size_t last = radices.size() - 1;
+      if (radices[last - 1] == 16 && (radices[last] == 2 || radices[last] == 4) && last - 1 == static_cast<size_t>(n256)) {
+        radices[last - 1] = 16 * radices[last];
+        radices.pop_back();
+      }
+    }
+    uint64_t ns = 1;
+    for (size_t i = 0; i < radices.size(); ++i) {
+      const int R = radices[i];
+      const bool last = (i + 1 == radices.size());
+      if (R == 256 || R == 512) {
+        const bool no_tw = variant & 128;   // debugging aid: WRONG results, timing/determinism only
+        passes.push_back(Pass{PassKind::Col256, R, ns, !last && !no_tw, false, last ? 0 : radices[i + 1]});
+      } else {
+        const bool prev_col = i > 0 && radices[i - 1] >= 256;
+        passes.push_back(Pass{PassKind::Stockham, R, ns, false, prev_col, 0});
+      }
+      ns *= static_cast<uint64_t>(R);
+    }
+  }
+}
+
 // Grid of a grid-stride ("persistent") kernel whose workgroups each own `iters` work items per wave slot: at least one
 // workgroup per CU's worth when there is that much work, otherwise blocks_needed / iters so that the hardware
 // dispatcher hands out workgroups as CUs drain (keeps CUs out of lock-step; see launch_k4096_v).
@@ -663,95 +746,20 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     (void)hipSetDevice(prev);
     return code;
   };
-  // ---- pass list. Radix-256 column passes first (they hand the next pass its twiddles), then
-  // radix-16 and one radix-2/4/8 autosort pass. variant bit 32 forces the plain autosort chain.
-  const int lg = ilog2(n);
-  const bool force_stockham = opts && (opts->variant & 32);
+  // ---- pass list (plan_passes: pure host logic, also behind tfft_plan_describe)
+  const int pvariant = opts ? opts->variant : 0;
+  plan_passes(n, inner, pvariant, p->passes);
   bool need_tables = false;
-  if (n == 4096 && inner == 1 && !force_stockham) {
-    p->passes.push_back(Pass{PassKind::K4096, 4096, 1, false, false, 0});
-    need_tables = true;
-  } else if (n == 256 && inner == 1 && !force_stockham) {
-    p->passes.push_back(Pass{PassKind::K256, 256, 1, false, false, 0});
-    need_tables = true;
-  } else if ((n == 8192 || n == 16384 || n == 32768) && inner == 1 && !force_stockham &&
-             !(opts && (opts->variant & 16777216))) {
-    // one pass: R waves share a transform, radix-R step in front of the 4096 kernel's stages (variant bit 16777216:
-    // the multi-pass column plan instead)
-    p->passes.push_back(Pass{PassKind::K4096R, static_cast<int>(n / 4096), 1, false, false, 0});
-    need_tables = true;
-  } else if ((n == 512 || n == 1024 || n == 2048) && inner == 1 && !force_stockham) {
-    const int R = static_cast<int>(n / 256);
-    p->passes.push_back(Pass{PassKind::K256R, R, 1, false, false, 0});
+  for (const Pass& ps : p->passes)
+    need_tables = need_tables || ps.kind == PassKind::K4096 || ps.kind == PassKind::K256 || ps.kind == PassKind::K4096R ||
+                  ps.kind == PassKind::Col256;
+  if (p->passes.size() == 1 && p->passes[0].kind == PassKind::K256R) {
     std::vector<uint8_t> blob;
-    k256r::build_tables(R, blob);
+    k256r::build_tables(p->passes[0].radix, blob);
     e = hipMalloc(&p->d_tables, blob.size());
     if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(tables)"));
     e = hipMemcpy(p->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tables)"));
-  } else {
-    int n256 = 0;
-    // radix-256 column passes wherever the geometry allows them (variant bit 32 = plain autosort chain)
-    const bool col_ok = !force_stockham && (inner == 1 ? lg >= 13 : (lg >= 8 && inner >= 16));
-    if (col_ok) n256 = lg / 8;
-    int rem = lg - 8 * n256;
-    std::vector<int> radices(n256, 256);
-    // Radix-512 column passes where they save a whole pass (2^15 = 512 x 64, 2^17 = 256 x 512, 2^18 = 512 x 512,
-    // 2^23 = 256 x 512 x 64, 2^25, 2^26 = 256 x 512 x 512, 2^27 = 512^3): the split lg = 8 a + 9 b + t, t <= 7, with the
-    // fewest passes (a tail of t bits costs 0 / 1 / 2 passes for t = 0 / 1..6 / 7); ties go to the fewest radix-512
-    // passes (their row segments are 128 bytes, not 256). variant bit 8388608 turns them off.
-    const bool use512 = col_ok && inner == 1 && lg >= 15 && !(opts && (opts->variant & 8388608));
-    if (use512) {
-      auto tail_cost = [](int t) { return t == 0 ? 0 : (t <= 6 ? 1 : 2); };
-      int best_a = n256, best_b = 0, best_cost = n256 + tail_cost(rem);
-      for (int b = 1; b <= 3; ++b)
-        for (int a2 = 0; 8 * a2 + 9 * b <= lg; ++a2) {
-          const int t = lg - 8 * a2 - 9 * b;
-          if (t > 7) continue;
-          const int cost = a2 + b + tail_cost(t);
-          if (cost < best_cost) {
-            best_cost = cost;
-            best_a = a2;
-            best_b = b;
-          }
-        }
-      n256 = best_a + best_b;               // column passes in total
-      radices.assign(best_a, 256);
-      radices.insert(radices.end(), best_b, 512);
-      rem = lg - 8 * best_a - 9 * best_b;
-    }
-    // n = 512 along a strided axis as ONE radix-512 column pass (variant bit 67108864; the second pass of the fused 2D plan)
-    if (n == 512 && inner >= 64 && (opts && (opts->variant & 67108864)) && !force_stockham) {
-      radices.assign(1, 512);
-      n256 = 1;
-      rem = 0;
-    }
-    for (; rem >= 4; rem -= 4) radices.push_back(16);
-    if (rem) radices.push_back(1 << rem);
-    // a radix-16 pass followed by a radix-2 / radix-4 pass behind a column pass fuses into one radix-32 / radix-64
-    // pass (the butterfly fits in registers; its input twiddles come from the column pass). variant bit 2097152 keeps them apart.
-    const bool fuse_tail = !(opts && (opts->variant & 2097152));
-    if (fuse_tail && n256 >= 1 && radices.size() >= static_cast<size_t>(n256) + 2) {
-      const size_t last = radices.size() - 1;
-      if (radices[last - 1] == 16 && (radices[last] == 2 || radices[last] == 4) && last - 1 == static_cast<size_t>(n256)) {
-        radices[last - 1] = 16 * radices[last];
-        radices.pop_back();
-      }
-    }
-    uint64_t ns = 1;
-    for (size_t i = 0; i < radices.size(); ++i) {
-      const int R = radices[i];
-      const bool last = (i + 1 == radices.size());
-      if (R == 256 || R == 512) {
-        const bool no_tw = opts && (opts->variant & 128);   // debugging aid: WRONG results, timing/determinism only
-        p->passes.push_back(Pass{PassKind::Col256, R, ns, !last && !no_tw, false, last ? 0 : radices[i + 1]});
-        need_tables = true;
-      } else {
-        const bool prev_col = i > 0 && radices[i - 1] >= 256;
-        p->passes.push_back(Pass{PassKind::Stockham, R, ns, false, prev_col, 0});
-      }
-      ns *= static_cast<uint64_t>(R);
-    }
   }
   if (need_tables) {
     std::vector<uint8_t> blob;
@@ -799,6 +807,28 @@ void tfft_plan_destroy(tfft_plan* p) {
   if (p->d_tw_hi) (void)hipFree(p->d_tw_hi);
   if (p->ws && p->ws_owned) (void)hipFree(p->ws);
   delete p;
+}
+
+int tfft_plan_describe(uint64_t n, uint64_t inner, int variant, char* buf, size_t bytes) {
+  g_err.clear();
+  if (!buf || bytes == 0) return fail(TFFT_ERR_ARG, "null buffer");
+  if (!is_pow2(n) || n < 2) return fail(TFFT_ERR_NOT_POW2, "Error! Input size has to be a power of 2!");
+  if (inner == 0) inner = 1;
+  if (!is_pow2(inner) || (inner > 1 && inner < 8)) return fail(TFFT_ERR_ARG, "inner (strided-axis batch) must be 1 or a power of two >= 8");
+  std::vector<Pass> passes;
+  plan_passes(n, inner, variant, passes);
+  std::string out;
+  for (const Pass& ps : passes) {
+    const char* k = ps.kind == PassKind::K4096 ? "k4096" : ps.kind == PassKind::K4096R ? "k4096r" : ps.kind == PassKind::K256 ? "k256"
+                    : ps.kind == PassKind::K256R ? "k256r" : ps.kind == PassKind::Col256 ? "col" : "autosort";
+    if (!out.empty()) out += " ";
+    out += std::string(k) + ":" + std::to_string(ps.radix);
+    if (ps.tw_next) out += "+tw";
+    if (ps.skip_tw) out += "-tw";
+  }
+  if (out.size() + 1 > bytes) return fail(TFFT_ERR_ARG, "buffer too small");
+  std::memcpy(buf, out.c_str(), out.size() + 1);
+  return TFFT_OK;
 }
 
 // passes over the data (a narrow column pass with a ragged batch takes two launches for its one pass)

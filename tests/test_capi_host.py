@@ -110,3 +110,58 @@ def test_product_never_touches_the_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, fn)
+
+
+def _radices(desc):
+    return [int(tok.split(":")[1].split("+")[0].split("-")[0]) for tok in desc.split()]
+
+
+def test_planner_decompositions_multiply_to_n():
+    """tfft_plan_describe (host only): for every power of two and a range of strided-axis widths and planner variants the
+    pass radices multiply to N, column passes come first, and only a pass directly behind a column pass skips its twiddles."""
+    import tensor_fft_amd as tf
+
+    for lg in range(1, 31):
+        n = 1 << lg
+        for inner in (1, 8, 16, 64, 4096):
+            for variant in (0, 32, 8388608, 16777216, 2097152, 16777216 | 8388608):
+                d = tf.plan_describe(n, inner, variant)
+                toks = d.split()
+                rad = _radices(d)
+                prod = 1
+                for r in rad:
+                    prod *= r
+                if toks[0].startswith(("k256r", "k4096r")):
+                    prod *= 256 if toks[0].startswith("k256r") else 4096
+                assert prod == n, (n, inner, variant, d)
+                kinds = [t.split(":")[0] for t in toks]
+                if "col" in kinds:
+                    last_col = max(i for i, k in enumerate(kinds) if k == "col")
+                    assert all(k == "col" for k in kinds[: last_col + 1]), d
+                for i, t in enumerate(toks):
+                    if t.endswith("-tw"):
+                        assert i > 0 and kinds[i - 1] == "col" and toks[i - 1].endswith("+tw"), d
+                    if t.endswith("+tw"):
+                        assert i + 1 < len(toks), d
+
+
+def test_planner_pass_counts():
+    """The pass counts DESIGN.md quotes: one pass up to 2^15, two up to 2^18, three up to 2^27 (contiguous axis)."""
+    import tensor_fft_amd as tf
+
+    want = {8: 1, 9: 1, 10: 1, 11: 1, 12: 1, 13: 1, 14: 1, 15: 1, 16: 2, 17: 2, 18: 2, 19: 3, 20: 3, 21: 3, 22: 3, 23: 3,
+            24: 3, 25: 3, 26: 3, 27: 3, 28: 4, 29: 4}
+    for lg, passes in want.items():
+        assert len(tf.plan_describe(1 << lg).split()) == passes, (lg, tf.plan_describe(1 << lg))
+    assert tf.plan_describe(1 << 12) == "k4096:4096"
+    assert tf.plan_describe(1 << 15) == "k4096r:8"
+    assert tf.plan_describe(1 << 17) == "col:256+tw col:512"
+    assert tf.plan_describe(1 << 20) == "col:256+tw col:256+tw autosort:16-tw"
+    assert tf.plan_describe(1 << 26) == "col:256+tw col:512+tw col:512"
+    assert tf.plan_describe(4096, 4096) == "col:256+tw autosort:16-tw"          # 2D column pass (general shapes)
+    assert tf.plan_describe(512, 4096, 67108864) == "col:512"                    # second pass of the fused 4096^2 plan
+    assert tf.plan_describe(1 << 13, 1, 16777216) == "col:256+tw autosort:32-tw"
+    assert tf.plan_describe(1 << 16, 1, 32) == "autosort:16 autosort:16 autosort:16 autosort:16"
+    with pytest.raises(tf.TfftError):
+        tf.plan_describe(3000)
+
