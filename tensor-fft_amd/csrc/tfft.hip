@@ -490,7 +490,12 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   const bool wg8_ok = (a.pitch % 128 == 0) && (a.ns_f == 1 || a.ns_f % 128 == 0);
   const bool wg4_ok = (a.pitch % 64 == 0) && (a.ns_f == 1 || a.ns_f % 64 == 0);
   // variant bit 524288: 4-wave workgroups (two per CU) instead of one 8-wave workgroup
-  static const uint32_t wg4_max_pitch = env_iters("TFFT_WG4_MAX_PITCH", 1024);   // experiment knob
+  static const uint32_t wg4_max_pitch_lanes = env_iters("TFFT_WG4_MAX_PITCH", 1024);          // experiment knobs
+  // (the columns-in-registers form, whose output is staged behind two more barriers, gains from two workgroups per
+  // CU up to a pitch of 16384: 2^20 x 1024 221.6 -> 228.9 Gsamples/s, 2^22 215.5 -> 220.1; beyond that the 128-byte
+  // segments lose more than the overlap gives: 2^24 194.6 -> 170.8)
+  static const uint32_t wg4_max_pitch_regs = env_iters("TFFT_WG4_MAX_PITCH_INREGS", 16384);
+  const uint32_t wg4_max_pitch = (a.ns_f == 1) ? wg4_max_pitch_lanes : wg4_max_pitch_regs;
   // ... also when 8-wave workgroups would leave CUs idle (single long transforms: 2^20 x 1 is 32 blocks of 128 columns)
   const bool few_blocks = entries * a.pitch / 128 < static_cast<uint64_t>(p->num_cus);
   if (wg_allowed && wg4_ok && ((p->variant & 524288) || !wg8_ok || a.pitch <= wg4_max_pitch || few_blocks))
