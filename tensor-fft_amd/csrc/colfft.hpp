@@ -528,11 +528,13 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
       }
       if (MODE == kColsInRegs) {
         // row k = ka + 16 kb (kb = x) of the shared output image, this wave's columns 16 wave + 4g .. + 3:
-        // chunk 2 wave + (g >> 1), bytes 8 (g & 1) of it
+        // chunk 2 wave + (g >> 1), bytes 8 (g & 1) of it. The OUTPUT image has its own swizzle, slot ^ kb over all four
+        // bits of kb: the 16 lanes of a group then hit 16 different slots (with the input image's 2 (kb & 7), lanes kb
+        // and kb + 8 collided: PMC showed bank-conflict cycles = 54 % of the LDS-active cycles of this kernel)
         const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
         const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
         uint8_t* dst = img + ((ka / kRps) + (16 / kRps) * x) * 256 +
-                       16 * (((ka % kRps) * kCpr + 2 * wave + (g >> 1)) ^ (2 * (x & 7))) + 8 * (g & 1);
+                       16 * (((ka % kRps) * kCpr + 2 * wave + (g >> 1)) ^ x) + 8 * (g & 1);
         *reinterpret_cast<u2*>(dst) = vr;
         *reinterpret_cast<u2*>(dst + kPlane) = vi;
       } else {
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint32_t sr = 32 * wave + 4 * i + (lane >> 4);
-        const uint32_t v = (lane & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
+        const uint32_t v = (lane & 15) ^ (((sr * kRps) >> 4) & 15);   // output image: slot ^ kb (see the stage-2 stores)
         const uint32_t k = sr * kRps + v / kCpr;
         const uint32_t chunk = v % kCpr;
         const u4 vr = *reinterpret_cast<const u4*>(img + 8192 * wave + 1024 * i + 16 * lane);
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
         const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
         const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
         uint8_t* dst = img_q + ((ka / kRps) + (16 / kRps) * x) * 256 +
-                       16 * (((ka % kRps) * kCpr + 2 * w4 + (g >> 1)) ^ (2 * (x & 7))) + 8 * (g & 1);
+                       16 * (((ka % kRps) * kCpr + 2 * w4 + (g >> 1)) ^ x) + 8 * (g & 1);
         *reinterpret_cast<u2*>(dst) = vr;
         *reinterpret_cast<u2*>(dst + kPlaneAll) = vi;
       } else if ((ka & 1) == 0) {
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     for (int it = 0; it < 4; ++it) {
       const uint32_t L = it * kThreads + tid;                  // 16-byte slot of the half-image
       const uint32_t sr = L >> 4;
-      const uint32_t v = (L & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
+      const uint32_t v = (L & 15) ^ (((sr * kRps) >> 4) & 15);   // output image: slot ^ kb
       const uint32_t k = sr * kRps + v / kCpr;
       const uint32_t chunk = v % kCpr;
       const u4 a_re = *reinterpret_cast<const u4*>(img + 16 * L);
