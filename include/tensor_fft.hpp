@@ -23,9 +23,11 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <sstream>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -49,6 +51,9 @@ struct Plan {
   int r16_gridsize_;
   int r16_shared_mem_in_bytes_;
   int r2_blocksize_;
+  // MI355X extension (not in the reference's struct): tuned kernel variant = sixth column of a tuner file written by
+  // tools/tuner.py (tfft_plan_opts.variant); 0 = library default. CreatePlan(N, mode, ...) leaves it 0.
+  int tfft_variant_ = 0;
 };
 
 template <typename Integer>
@@ -100,7 +105,9 @@ std::optional<Plan<Integer>> CreatePlan(const Integer fft_length, const BaseFFTM
 }
 
 // Tuner-file overload: first line whose leading number equals fft_length, fields
-// `N mode base_wpb r16_wpb r2_blocksize` with mode written as 256 or 4096.
+// `N mode base_wpb r16_wpb r2_blocksize` with mode written as 256 or 4096, and optionally the sixth column
+// tools/tuner.py appends (the tuned kernel variant; checked with tfft_variant_check, a line with an unusable
+// value is refused like a missing line).
 template <typename Integer>
 std::optional<Plan<Integer>> CreatePlan(const Integer fft_length, const std::string tuner_results_file) {
   std::ifstream file(tuner_results_file);
@@ -115,7 +122,16 @@ std::optional<Plan<Integer>> CreatePlan(const Integer fft_length, const std::str
     int mode_num, bw, rw, r2;
     if (!(ss >> len >> mode_num >> bw >> rw >> r2)) continue;
     if (static_cast<Integer>(len) != fft_length) continue;
-    return CreatePlan(fft_length, mode_num == 256 ? Mode_256 : Mode_4096, bw, rw, r2);
+    auto plan = CreatePlan(fft_length, mode_num == 256 ? Mode_256 : Mode_4096, bw, rw, r2);
+    int variant = 0;
+    if (plan && (ss >> variant)) {
+      if (tfft_variant_check(static_cast<uint64_t>(fft_length), 1, variant) != TFFT_OK) {
+        std::cout << "Error! Tuner file holds an unusable kernel variant for this fft length: " << tfft_last_error() << std::endl;
+        return std::nullopt;
+      }
+      plan->tfft_variant_ = variant;
+    }
+    return plan;
   }
   std::cout << "Error! Tuner file didnt contain requested fft length." << std::endl;
   return std::nullopt;
@@ -137,20 +153,25 @@ inline std::optional<std::string> hip_status(hipError_t e) {
 }
 inline std::optional<std::string> peek() { return hip_status(hipPeekAtLastError()); }
 
-// One execution plan per (N, batch, device), kept for the life of the process so that
-// ComputeFFT stays a pure launch, like the reference's.
-inline tfft_plan* exec_plan(uint64_t n, uint64_t batch, std::string* err) {
-  static std::map<std::tuple<uint64_t, uint64_t, int>, tfft_plan*> cache;
+// One execution plan per (N, batch, device, variant), kept for the life of the process so that
+// ComputeFFT stays a pure launch, like the reference's. The cache is shared by all host threads (a tfft_plan is
+// immutable and thread-safe, tfft.h), hence the lock.
+inline tfft_plan* exec_plan(uint64_t n, uint64_t batch, int variant, std::string* err) {
+  static std::mutex lock;
+  static std::map<std::tuple<uint64_t, uint64_t, int, int>, tfft_plan*> cache;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) {
     *err = "hipGetDevice failed";
     return nullptr;
   }
-  const auto key = std::make_tuple(n, batch, dev);
+  const auto key = std::make_tuple(n, batch, dev, variant);
+  std::lock_guard<std::mutex> guard(lock);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
+  tfft_plan_opts opts{};
+  opts.variant = variant;
   tfft_plan* p = nullptr;
-  if (tfft_plan_create(n, batch, dev, nullptr, &p) != TFFT_OK) {
+  if (tfft_plan_create(n, batch, dev, &opts, &p) != TFFT_OK) {
     *err = tfft_last_error();
     return nullptr;
   }
@@ -250,7 +271,7 @@ template <typename Integer>
 std::optional<std::string> ComputeFFT(Plan<Integer>& fft_plan, const DataHandler<Integer>& data,
                                       const int /*max_no_optin_shared_mem*/ = 32768) {
   std::string err;
-  tfft_plan* p = tfft_detail::exec_plan(static_cast<uint64_t>(fft_plan.fft_length_), 1, &err);
+  tfft_plan* p = tfft_detail::exec_plan(static_cast<uint64_t>(fft_plan.fft_length_), 1, fft_plan.tfft_variant_, &err);
   if (!p) return err;
   __half* out_re = fft_plan.results_in_results_ ? data.dptr_results_RE_ : data.dptr_input_RE_;
   __half* out_im = fft_plan.results_in_results_ ? data.dptr_results_IM_ : data.dptr_input_IM_;
@@ -266,7 +287,7 @@ std::optional<std::string> ComputeFFT(const Plan<Integer>& fft_plan, const DataB
                                       const int /*max_no_optin_shared_mem*/ = 32768) {
   std::string err;
   tfft_plan* p = tfft_detail::exec_plan(static_cast<uint64_t>(fft_plan.fft_length_),
-                                        static_cast<uint64_t>(data.amount_of_ffts_), &err);
+                                        static_cast<uint64_t>(data.amount_of_ffts_), fft_plan.tfft_variant_, &err);
   if (!p) return err;
   __half* out_re = fft_plan.results_in_results_ ? data.dptr_results_RE_[0] : data.dptr_input_RE_[0];
   __half* out_im = fft_plan.results_in_results_ ? data.dptr_results_IM_[0] : data.dptr_input_IM_[0];

@@ -101,18 +101,65 @@ typedef struct tfft_plan_opts {
   int preserve_input;   /* 0: the input planes may be used as scratch, exactly as the
                            reference does (ComputeFFT.h:89-93,118-119); 1: never written */
   int variant;          /* tuner / experiment knob, 0 = default (what tools/tuner.py writes as the sixth column).
+                           Every value accepted here yields CORRECT spectra; bits select between equivalent kernels:
                            N == 4096 kernel: mask of 1 = prefetch the next transform under stages 2/3, 2 = stage
                            the output through LDS (full-row stores), 8 = non-temporal loads/stores, 16 = none of
-                           these (default = 2|8); 4 and 64 are timing-only (WRONG results).
+                           these (default = 2|8; 1 and 2 exclude each other).
                            Any N: 32 = plain autosort chain (no column kernel); 2097152 = do not fuse the
                            radix-16 + radix-2/4 tail into one radix-32/64 pass; 8388608 = no radix-512 column
                            passes; 16777216 = N = 8192..32768 as a column plan instead of the single-pass kernel; 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
                            Column passes: 131072 = per-wave kernel, 524288 = 4-wave cooperative workgroups,
                            262144 = no non-temporal accesses, 1048576 = 16-byte stores straight from registers,
                            4096 / 8192 = per-wave kernel with LDS-staged stores / hardware sin-cos twiddles.
-                           Debugging aids (WRONG or partial results): (p << 8), p = 1..15: run only the first
-                           p passes; 128 = skip inter-pass twiddles; 65536 = copy-only column pass. */
+                           Unknown bits are rejected (TFFT_ERR_ARG), see tfft_variant_check().
+                           Timing / debugging aids that give WRONG or partial results are NOT part of this field's
+                           accepted values: 4 and 64 (N == 4096 kernel: fake stores / no compute), (p << 8), p = 1..15 (run
+                           only the first p passes), 128 (skip inter-pass twiddles), 65536 (copy-only column pass).
+                           They are honoured only when the environment variable TFFT_DEBUG_VARIANTS=1 is set in the
+                           process that creates the plan (tools/pass_breakdown.py, tools/exp_bench.py); otherwise
+                           tfft_plan_create() refuses them, so a stale tuner file cannot produce garbage silently. */
+  int scale;            /* TFFT_SCALE_* below; 0 = the reference's sequential scaling, result DFT(x)/N */
+  int output_order;     /* TFFT_ORDER_* below; 0 = natural order */
+  uint64_t fourstep_n;  /* 0 = off. Otherwise (n = 256 or 512, inner = C >= 64 columns): output row k of column c is also
+                           multiplied by w_M^(k (fourstep_col0 + c)), M = fourstep_n (a power of two >= n): the twiddle
+                           step between the two FFT passes of a four-step transform of length M, fused into the column
+                           pass. What TFFT_ORDER_TRANSPOSED plans use internally and what a transform distributed over
+                           several GPUs needs in front of its all-to-all (tensor-fft_amd/distributed.py) */
+  uint64_t fourstep_col0;
 } tfft_plan_opts;
+
+/* tfft_plan_opts.scale — where the 1/N goes. The reference ships "sequential scaling" and keeps the other two as
+ * commented-out variants (src/base/TensorFFT256.cu:163-177 "For unscaled results" / "For scaling in one step",
+ * Radix2.cu:56-65). All three differ only by exact powers of two, so away from overflow / underflow they give the
+ * same significands; what differs is the range of the fp16 intermediates:
+ *   SEQUENTIAL  every radix-R stage divides by R: |intermediate| <= max|x| at every stage, no finite input overflows.
+ *   NONE        no stage scales: result = DFT(x) (the cuFFT / hipFFT convention). fp16 intermediates grow by the
+ *               radix per stage; nothing overflows as long as N * max|x| <= 65504 (worst case: a constant or a pure
+ *               tone; white noise of rms s needs about 6 s sqrt(N) <= 65504). Beyond that the result holds inf / nan.
+ *   ONCE        one scaling step: every stage unscaled and a single exact factor 1/N applied in fp32 at the last fp32
+ *               multiply of the plan (the inter-stage twiddle of its last kernel). Result = DFT(x)/N. Small inputs
+ *               keep their precision longest (nothing is pushed towards fp16 subnormals before the last stage); the
+ *               stages in front of the scaling step can overflow when 16^s * max|x| > 65504 (s = stages before it). */
+enum { TFFT_SCALE_SEQUENTIAL = 0, TFFT_SCALE_NONE = 1, TFFT_SCALE_ONCE = 2 };
+
+/* tfft_plan_opts.output_order.
+ *   NATURAL      out[k] = X[k] (what the reference produces, TensorRadix16.cu:169-213).
+ *   TRANSPOSED   N = N1 * N2 (N2 = tfft_plan_transposed_n2(n), N1 = N / N2): out[k1 * N2 + k2] = X[k1 + N1 * k2], i.e.
+ *                the [N1][N2] matrix of the four-step algorithm left un-transposed (the order DistributedFFT1D's
+ *                "transposed" layout has). For 2^16 <= N <= 2^24 this takes TWO passes over HBM (one strided radix-N1
+ *                column pass that also applies w_N^(k1 n2), one contiguous N2-point pass) where natural order needs
+ *                three from 2^19 on: for callers that multiply spectra pointwise and transform back, or that index
+ *                the spectrum through the map above. Lengths without a two-pass split fall back to NATURAL
+ *                (tfft_plan_transposed_n2(n) == 0). Needs a workspace (tfft_plan_workspace_bytes). */
+enum { TFFT_ORDER_NATURAL = 0, TFFT_ORDER_TRANSPOSED = 1 };
+
+/* Host only. N2 of the TRANSPOSED order for length n (0: no two-pass split, natural order is produced). */
+uint64_t tfft_plan_transposed_n2(uint64_t n);
+
+/* Host only: TFFT_OK if `variant` is acceptable to tfft_plan_create for (n, inner): only documented bits, no
+ * combination without a compiled kernel, and no WRONG-result debugging bit unless TFFT_DEBUG_VARIANTS=1 is set.
+ * CreatePlan(N, tuner_file) of the shims runs it on the file's sixth column. */
+int tfft_variant_check(uint64_t n, uint64_t inner, int variant);
 
 int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts,
                      tfft_plan** out);

@@ -52,6 +52,8 @@ def lib():
         L.orc_ref_fft.argtypes = [u64, u64, ctypes.c_int, u16p, u16p, u64, u16p, u16p, u64]
         L.orc_dft64.restype = ctypes.c_int
         L.orc_dft64.argtypes = [u64, u64, u16p, u16p, u64, f64p, f64p, u64, ctypes.c_int, ctypes.c_int]
+        L.orc_fft64_rows.restype = ctypes.c_int
+        L.orc_fft64_rows.argtypes = [u64, u64, f64p, f64p, u64]
         L.orc_random_weights.restype = None
         L.orc_random_weights.argtypes = [ctypes.c_int, ctypes.c_int, f32p]
         L.orc_sine_superposition.restype = None
@@ -124,6 +126,18 @@ def dft64(re, im, algo=1, threads=0):
     if rc:
         raise ValueError(f"orc_dft64 rc={rc}")
     return orr, oi
+
+
+def fft64_rows(z):
+    """fp64 DFT/N along the last axis of a complex128 array (oracle radix-2 FFT); returns a new array."""
+    z = np.asarray(z, dtype=np.complex128)
+    n = z.shape[-1]
+    re = np.ascontiguousarray(z.real).reshape(-1, n)
+    im = np.ascontiguousarray(z.imag).reshape(-1, n)
+    rc = lib().orc_fft64_rows(n, re.shape[0], _f64(re), _f64(im), n)
+    if rc:
+        raise ValueError(f"orc_fft64_rows rc={rc}")
+    return (re + 1j * im).reshape(z.shape)
 
 
 def random_weights(count, seed):

@@ -514,6 +514,33 @@ int orc_dft64(uint64_t n, uint64_t batch, const uint16_t* in_re, const uint16_t*
   return 0;
 }
 
+// fp64 in, fp64 out, in place: x <- DFT(x)/N per row of a [batch][n] array (radix-2). The second axis of a 2D oracle
+// transform, whose input is the fp64 result of the first axis (no reference counterpart: the reference's oracle is
+// cuFFT Z2Z, CuFFTTest.h:218-261).
+int orc_fft64_rows(uint64_t n, uint64_t batch, double* re, double* im, uint64_t stride) {
+  if (n == 0 || (n & (n - 1))) return 1;
+  std::vector<double> wr(n), wi(n);
+  for (uint64_t k = 0; k < n; ++k) {
+    const double ang = -2.0 * M_PI * static_cast<double>(k) / static_cast<double>(n);
+    wr[k] = std::cos(ang);
+    wi[k] = std::sin(ang);
+  }
+  const double inv = 1.0 / static_cast<double>(n);
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t b = 0; b < static_cast<int64_t>(batch); ++b) {
+    std::vector<double>& ar = scratch_re();
+    std::vector<double>& ai = scratch_im();
+    ar.assign(re + b * stride, re + b * stride + n);
+    ai.assign(im + b * stride, im + b * stride + n);
+    fft64_inplace(ar, ai, wr, wi);
+    for (uint64_t k = 0; k < n; ++k) {
+      re[b * stride + k] = ar[k] * inv;
+      im[b * stride + k] = ai[k] * inv;
+    }
+  }
+  return 0;
+}
+
 // GetRandomWeights (TestingDataCreation.h:15-27): same std:: machinery.
 void orc_random_weights(int count, int seed, float* out) {
   std::seed_seq seq = {seed};

@@ -19,7 +19,13 @@ SYMBOLS = [
     "tfft_last_error", "tfft_version", "tfft_permute_twiddle", "tfft_exec_inverse", "tfft_deinterleave", "tfft_interleave",
     "tfft_plan2d_create", "tfft_plan2d_destroy", "tfft_plan2d_num_launches", "tfft_plan2d_workspace_bytes",
     "tfft_plan2d_set_workspace", "tfft_plan2d_exec", "tfft_plan2d_exec_inverse", "tfft_plan_describe",
+    "tfft_variant_check", "tfft_plan_transposed_n2",
 ]
+
+SCALE_SEQUENTIAL, SCALE_NONE, SCALE_ONCE = 0, 1, 2           # tfft_plan_opts.scale
+ORDER_NATURAL, ORDER_TRANSPOSED = 0, 1                        # tfft_plan_opts.output_order
+_SCALES = {"sequential": 0, "none": 1, "once": 2}
+_ORDERS = {"natural": 0, "transposed": 1}
 
 
 class TfftError(RuntimeError):
@@ -56,6 +62,10 @@ class PlanOpts(ctypes.Structure):
         ("inner", ctypes.c_uint64),
         ("preserve_input", ctypes.c_int),
         ("variant", ctypes.c_int),
+        ("scale", ctypes.c_int),
+        ("output_order", ctypes.c_int),
+        ("fourstep_n", ctypes.c_uint64),
+        ("fourstep_col0", ctypes.c_uint64),
     ]
 
 
@@ -125,6 +135,10 @@ def load_library():
     L.tfft_plan2d_exec_inverse.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tfft_plan_describe.restype = ci
     L.tfft_plan_describe.argtypes = [u64, u64, ci, ctypes.c_char_p, ctypes.c_size_t]
+    L.tfft_variant_check.restype = ci
+    L.tfft_variant_check.argtypes = [u64, u64, ci]
+    L.tfft_plan_transposed_n2.restype = u64
+    L.tfft_plan_transposed_n2.argtypes = [u64]
     L.tfft_plan_kernel_name.restype = ctypes.c_char_p
     L.tfft_plan_kernel_name.argtypes = [vp]
     L.tfft_plan_algorithmic_bytes.restype = ctypes.c_double
@@ -155,6 +169,16 @@ def plan_describe(n, inner=1, variant=0):
     return buf.value.decode()
 
 
+def variant_check(n, inner=1, variant=0):
+    """tfft_variant_check: raises TfftError unless `variant` is a value tfft_plan_create accepts. Host only."""
+    _check(load_library().tfft_variant_check(int(n), int(inner), int(variant)))
+
+
+def transposed_n2(n):
+    """N2 of the TRANSPOSED output order (out[k1 * N2 + k2] = X[k1 + (N / N2) * k2]); 0 = natural order only."""
+    return int(load_library().tfft_plan_transposed_n2(int(n)))
+
+
 def ref_create_plan(fft_length, mode=0, base_fft_warps_per_block=8, r16_warps_per_block=8, r2_blocksize=256):
     """tfft_ref_create_plan -> (rc, RefPlanStruct, message). Host only, no GPU needed."""
     L = load_library()
@@ -172,11 +196,15 @@ class TfftPlan:
     """Owning wrapper of tfft_plan. exec() takes torch CUDA half tensors (planar)."""
 
     def __init__(self, n, batch=1, device=0, in_batch_stride=0, out_batch_stride=0, preserve_input=False,
-                 variant=0, inner=1):
+                 variant=0, inner=1, scale="sequential", output_order="natural", fourstep_n=0, fourstep_col0=0):
         L = load_library()
         self._lib = L
         self._h = ctypes.c_void_p()
-        opts = PlanOpts(int(in_batch_stride), int(out_batch_stride), int(inner), int(bool(preserve_input)), int(variant))
+        scale = _SCALES[scale] if isinstance(scale, str) else int(scale)
+        output_order = _ORDERS[output_order] if isinstance(output_order, str) else int(output_order)
+        opts = PlanOpts(int(in_batch_stride), int(out_batch_stride), int(inner), int(bool(preserve_input)), int(variant),
+                        scale, output_order, int(fourstep_n), int(fourstep_col0))
+        self.scale, self.output_order = scale, output_order
         _check(L.tfft_plan_create(int(n), int(batch), int(device), ctypes.byref(opts), ctypes.byref(self._h)))
         self.n, self.batch, self.device, self.inner = int(n), int(batch), int(device), int(inner)
         self.in_batch_stride = int(in_batch_stride) or 2 * self.n * self.inner

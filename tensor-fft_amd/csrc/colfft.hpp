@@ -66,7 +66,19 @@ struct Args {
   const float2* tw_lo;
   const float2* tw_hi;
   const uint8_t* tables;            // k4096::build_tables blob
+  // tfft_plan_opts.scale (include/tfft.h): tw_scale multiplies the twiddles a TW pass applies (1, or the plan's single
+  // 1/N of "scale once" when this is the plan's last fp32 multiply); comb_scale is the factor of the radix-512 pass's
+  // fp32 radix-2 combine (1/2 for sequential scaling)
+  float tw_scale;
+  float comb_scale;
+  // TW == kTwFourStep: output row k of flattened column m is multiplied by w_M^(k (tw4_col0 + m)), M = n_mask + 1 (the
+  // twiddle tables are then built for M, the length of the whole four-step transform, not for this pass's radix):
+  // the w_N^(k1 n2) step of a transform split as N = N1 N2 (transposed-order plans, local passes of a distributed one)
+  uint64_t tw4_col0;
 };
+
+// twiddle forms of a column pass: none, the next autosort pass's input twiddles, the four-step twiddle
+enum : int { kTwNone = 0, kTwNext = 1, kTwFourStep = 2 };
 
 struct cpx {
   float re, im;
@@ -93,8 +105,19 @@ __device__ __forceinline__ cpx lookup(const Args& a, uint64_t e_t) {
   return cpx{__builtin_amdgcn_cosf(frac), -__builtin_amdgcn_sinf(frac)};
 }
 
-template <int MODE, bool TW, bool STAGE, bool LUT>
+__device__ __forceinline__ cpx lookup_n(const Args& a, uint64_t e_n) {   // w_N^(e_n), e_n already reduced mod N
+  const float2 lo = a.tw_lo[e_n & 8191];
+  cpx w = {lo.x, lo.y};
+  if (a.n_mask >= 8192) {
+    const float2 hi = a.tw_hi[e_n >> 13];
+    w = cmul(w, cpx{hi.x, hi.y});
+  }
+  return w;
+}
+
+template <int MODE, int TW, bool STAGE, bool LUT>
 __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
+  static_assert(TW == kTwNone || TW == kTwNext, "the per-wave kernel has no four-step twiddle form");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -158,6 +181,8 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
                                    ? (((m0 + x) - (rest_l << a.ns_f_shift)) >> a.inner_shift)
                                    : ((kprev_f0 + 4 * g + r) >> a.inner_shift);
         base[r] = lookup<LUT>(a, (av * ((kprev + a.ns * 16 * kb) & a.t_mask)) & a.t_mask);
+        base[r].re *= a.tw_scale;
+        base[r].im *= a.tw_scale;
       }
     }
 
@@ -337,8 +362,9 @@ constexpr int kWgLdsBytes = WgGeom<8>::kLds;
 
 // STG (columns-on-lanes form only): stage a wave's 16 output rows (one per column, 512 contiguous bytes each)
 // through its own 8-KiB slice of the image and store them as full rows, instead of 16-byte pieces from registers.
-template <int MODE, bool TW, bool NT, int W, bool STG = false>
+template <int MODE, int TW, bool NT, int W, bool STG = false>
 __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
+  static_assert(TW != kTwFourStep || MODE == kColsInRegs, "the four-step twiddle exists for the columns-in-registers form");
   using G = WgGeom<W>;
   constexpr int kPlane = G::kPlane, kRps = G::kRps, kCpr = G::kCpr;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -424,7 +450,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
     const uint64_t rest = m0 >> a.ns_f_shift;
     const uint64_t kprev_f0 = m0 - (rest << a.ns_f_shift);
     cpx base[4], step = {1.f, 0.f};
-    if (TW) {
+    cpx step4[4];                            // four-step form: one step per column
+    if (TW == kTwNext) {
       const uint64_t rest_l = (MODE == kColsOnLanes) ? ((m0 + x) >> a.ns_f_shift) : rest;
       const uint64_t av = rest_l >> a.a_shift;
       step = lookup<true>(a, (av * (a.ns & a.t_mask)) & a.t_mask);
@@ -435,6 +462,19 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
                                    ? (((m0 + x) - (rest_l << a.ns_f_shift)) >> a.inner_shift)
                                    : ((kprev_f0 + 4 * g + r) >> a.inner_shift);
         base[r] = lookup<true>(a, (av * ((kprev + a.ns * 16 * kb) & a.t_mask)) & a.t_mask);
+        base[r].re *= a.tw_scale;
+        base[r].im *= a.tw_scale;
+      }
+    }
+    if (TW == kTwFourStep) {
+      // w_M^(k col), k = ka + 16 kb (kb = x), col = tw4_col0 + m0 + 4 g + r: base = w_M^(16 x col), step = w_M^col
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint64_t col = a.tw4_col0 + m0 + 4 * g + r;
+        step4[r] = lookup_n(a, col & a.n_mask);
+        base[r] = lookup_n(a, (col * (16 * x)) & a.n_mask);
+        base[r].re *= a.tw_scale;
+        base[r].im *= a.tw_scale;
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -515,7 +555,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         e_re = mfma(dop, __builtin_bit_cast(h8, graw));
         e_im = mfma(dop, im_form(graw));
       }
-      if (TW) {
+      if (TW == kTwNext) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const cpx w = cmul(base[r], pw);
@@ -525,6 +565,16 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
           e_im[r] = vi;
         }
         pw = cmul(pw, step);
+      }
+      if (TW == kTwFourStep) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float vr = e_re[r] * base[r].re - e_im[r] * base[r].im;
+          const float vi = e_re[r] * base[r].im + e_im[r] * base[r].re;
+          e_re[r] = vr;
+          e_im[r] = vi;
+          base[r] = cmul(base[r], step4[r]);       // next tile: k + 1
+        }
       }
       if (MODE == kColsInRegs) {
         // row k = ka + 16 kb (kb = x) of the shared output image, this wave's columns 16 wave + 4g .. + 3:
@@ -632,15 +682,6 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
 // ---------------------------------------------------------------------------
 constexpr int kWg512LdsBytes = kLdsTable + 4 * WgGeom<4>::kPlane;   // 144 KiB
 
-__device__ __forceinline__ cpx lookup_n(const Args& a, uint64_t e_n) {   // w_N^(e_n), e_n already reduced mod N
-  const float2 lo = a.tw_lo[e_n & 8191];
-  cpx w = {lo.x, lo.y};
-  if (a.n_mask >= 8192) {
-    const float2 hi = a.tw_hi[e_n >> 13];
-    w = cmul(w, cpx{hi.x, hi.y});
-  }
-  return w;
-}
 
 // Next-pass twiddles of the radix-512 read-out: v_sin / v_cos (absolute error ~1e-6, three orders below binary16's
 // resolution) instead of the two-level fp32 tables: measured +3-6 % on 2^15 / 2^18 (six dependent loads per chunk less).
@@ -649,8 +690,9 @@ __device__ __forceinline__ cpx lookup_n(const Args& a, uint64_t e_n) {   // w_N^
 #endif
 constexpr bool kLut512 = TFFT_LUT512;
 
-template <int MODE, bool TW>
+template <int MODE, int TW>
 __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
+  static_assert(TW != kTwFourStep || MODE == kColsInRegs, "the four-step twiddle exists for the columns-in-registers form");
   using G = WgGeom<4>;
   constexpr int kHalf = G::kPlane;        // one sequence, one plane: 256 rows x 128 B
   constexpr int kPlaneAll = 2 * kHalf;    // RE -> IM distance
@@ -839,15 +881,17 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
         for (int e = 0; e < 8; ++e) {
           const float Ar = static_cast<float>(ar[e]), Br = static_cast<float>(br[e]);
           const float Ai = static_cast<float>(ai[e]), Bi = static_cast<float>(bi[e]);
-          x0r[e] = 0.5f * (Ar + Br);
-          x0i[e] = 0.5f * (Ai + Bi);
-          x1r[e] = 0.5f * (Ar - Br);
-          x1i[e] = 0.5f * (Ai - Bi);
+          x0r[e] = a.comb_scale * (Ar + Br);
+          x0i[e] = a.comb_scale * (Ai + Bi);
+          x1r[e] = a.comb_scale * (Ar - Br);
+          x1i[e] = a.comb_scale * (Ai - Bi);
         }
         if (TW) {
           const uint64_t av = (mb + f) >> a.a_shift;
           const cpx w1 = lookup<kLut512>(a, av & a.t_mask);
           cpx t0 = lookup<kLut512>(a, (av * k0) & a.t_mask);
+          t0.re *= a.tw_scale;
+          t0.im *= a.tw_scale;
           cpx t1 = cmul(t0, lookup<kLut512>(a, (av * 256) & a.t_mask));
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -883,11 +927,12 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     const uint64_t obase = ((restb << 9) << a.ns_f_shift) + (mb - (restb << a.ns_f_shift));
     cpx w_av = {1.f, 0.f}, w_half = {1.f, 0.f};
     uint64_t av = 0;
-    if (TW) {
+    if (TW == kTwNext) {
       av = restb >> a.a_shift;
       w_av = lookup<kLut512>(a, av & a.t_mask);                                            // w_T^av (per unit of kprev)
       w_half = lookup<kLut512>(a, (av * ((a.ns * 256) & a.t_mask)) & a.t_mask);            // w_T^(av ns 256)
     }
+    const float inv_m = 1.0f / static_cast<float>(a.n_mask + 1);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const uint32_t L = it * kThreads + tid;                  // 16-byte slot of the half-image
@@ -906,17 +951,41 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       for (int e = 0; e < 8; ++e) {
         const float Ar = static_cast<float>(ar[e]), Br = static_cast<float>(br[e]);
         const float Ai = static_cast<float>(ai[e]), Bi = static_cast<float>(bi[e]);
-        x0r[e] = 0.5f * (Ar + Br);
-        x0i[e] = 0.5f * (Ai + Bi);
-        x1r[e] = 0.5f * (Ar - Br);
-        x1i[e] = 0.5f * (Ai - Bi);
+        x0r[e] = a.comb_scale * (Ar + Br);
+        x0i[e] = a.comb_scale * (Ai + Bi);
+        x1r[e] = a.comb_scale * (Ar - Br);
+        x1i[e] = a.comb_scale * (Ai - Bi);
       }
-      if (TW) {
+      if (TW == kTwFourStep) {
+        // rows k and k + 256 of column c_e = tw4_col0 + mb + 8 chunk + e: t0(e) = w_M^(k c_e), t1(e) = t0(e) w_M^(256 c_e);
+        // both run along e as recurrences (steps w_M^k and w_M^256). v_sin / v_cos on exactly reduced exponents.
+        const uint64_t c0 = a.tw4_col0 + mb + 8 * chunk;
+        auto wm = [&](uint64_t e) {
+          const float frac = static_cast<float>(e & a.n_mask) * inv_m;
+          return cpx{__builtin_amdgcn_cosf(frac), -__builtin_amdgcn_sinf(frac)};
+        };
+        cpx t0 = wm(c0 * k), u = wm(c0 * 256);
+        t0.re *= a.tw_scale;
+        t0.im *= a.tw_scale;
+        const cpx sk = wm(k), s256 = wm(256);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const cpx t1 = cmul(t0, u);
+          const float r0 = x0r[e] * t0.re - x0i[e] * t0.im, i0 = x0r[e] * t0.im + x0i[e] * t0.re;
+          const float r1 = x1r[e] * t1.re - x1i[e] * t1.im, i1 = x1r[e] * t1.im + x1i[e] * t1.re;
+          x0r[e] = r0; x0i[e] = i0; x1r[e] = r1; x1i[e] = i1;
+          t0 = cmul(t0, sk);
+          u = cmul(u, s256);
+        }
+      }
+      if (TW == kTwNext) {
         // E = av (kprev + ns k') mod T; kprev of column e of this chunk = (kprev_f0 + e) >> inner_shift
         const uint64_t kprev_f0 = (mb + 8 * chunk) - (restb << a.ns_f_shift);
         const cpx row0 = lookup<kLut512>(a, (av * ((a.ns * k) & a.t_mask)) & a.t_mask);
         const cpx row1 = cmul(row0, w_half);
         cpx col = lookup<kLut512>(a, (av * ((kprev_f0 >> a.inner_shift) & a.t_mask)) & a.t_mask);
+        col.re *= a.tw_scale;
+        col.im *= a.tw_scale;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const cpx t0 = cmul(col, row0), t1 = cmul(col, row1);

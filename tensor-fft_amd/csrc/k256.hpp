@@ -31,8 +31,8 @@ constexpr int kFftsPerWave = 16;
 // in_*/out_*: planar binary16; transform b at +b*stride halves. tables: k4096::build_tables() blob
 // (uses the natural-order F operand forms and the w256 twiddle block).
 __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_re, const uint16_t* in_im,
-                                                             uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
-                                                             uint64_t out_stride, uint32_t batch,
+                                                             uint16_t* out_re, uint16_t* out_im, Addr in_map,
+                                                             Addr out_map, uint32_t batch,
                                                              const uint8_t* __restrict__ tables) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
     for (int t = 0; t < kFftsPerWave; ++t) {
       // transforms past the end of the batch re-read the last valid one (their results are not stored)
       const uint32_t b = b0 + (static_cast<uint32_t>(t) < nb ? t : nb - 1);
-      const uint16_t* src = in_plane + static_cast<uint64_t>(b) * in_stride + in_lane;
+      const uint16_t* src = in_plane + in_map.off(b) + in_lane;
       const uint32_t d = wl_off + t * 1024;
       uint32_t keep;
       asm volatile(
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
     for (int t = 0; t < kFftsPerWave; ++t) {
       const u4 v = *reinterpret_cast<const u4*>(wl + t * 1024 + 16 * lane);
       if (static_cast<uint32_t>(t) < nb) {
-        uint16_t* dst = ((lane < 32) ? out_re : out_im) + static_cast<uint64_t>(b0 + t) * out_stride + 8 * (lane & 31);
+        uint16_t* dst = ((lane < 32) ? out_re : out_im) + out_map.off(b0 + t) + 8 * (lane & 31);
         __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
       }
     }

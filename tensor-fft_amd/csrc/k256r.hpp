@@ -47,7 +47,10 @@ __host__ __device__ constexpr int slot_n0(int R, int g, int j) {
 // swizzle of the 32-byte blocks of row n1
 __host__ __device__ constexpr int swz(int R, int n1) { return (n1 >> (R == 2 ? 2 : (R == 4 ? 1 : 0))) & (R - 1); }
 
-inline void build_tables(int R, std::vector<uint8_t>& blob) {
+// fa, fb: factors on the stage-1 / stage-2 matrices (1/16 each for sequential scaling); s_scale: factor of the fp32
+// inter-stage twiddle block S (1/R for sequential scaling: the radix-R step's share)
+inline void build_tables(int R, std::vector<uint8_t>& blob, double fa = 1.0 / 16, double fb = 1.0 / 16, double s_scale = -1.0) {
+  if (s_scale < 0) s_scale = 1.0 / R;
   const int bytes = kOffS + 2048 * R + 2048 * (R - 1);
   blob.assign(bytes, 0);
   auto put_h = [&](int off, double v) {
@@ -71,24 +74,24 @@ inline void build_tables(int R, std::vector<uint8_t>& blob) {
       double c, s;
       cexp(static_cast<long>(4 * g + j) * x, 16, c, s);
       int base = kOffFa + lane * 32;
-      put_h(base + 2 * j, c / 16);
-      put_h(base + 2 * (4 + j), -s / 16);
-      put_h(base + 16 + 2 * j, s / 16);
-      put_h(base + 16 + 2 * (4 + j), c / 16);
+      put_h(base + 2 * j, c * fa);
+      put_h(base + 2 * (4 + j), -s * fa);
+      put_h(base + 16 + 2 * j, s * fa);
+      put_h(base + 16 + 2 * (4 + j), c * fa);
       cexp(static_cast<long>(slot_n0(R, g, j)) * x, 16, c, s);
       base = kOffFb + lane * 32;
-      put_h(base + 2 * j, c / 16);
-      put_h(base + 2 * (4 + j), -s / 16);
-      put_h(base + 16 + 2 * j, s / 16);
-      put_h(base + 16 + 2 * (4 + j), c / 16);
+      put_h(base + 2 * j, c * fb);
+      put_h(base + 2 * (4 + j), -s * fb);
+      put_h(base + 16 + 2 * j, s * fb);
+      put_h(base + 16 + 2 * (4 + j), c * fb);
     }
     for (int u = 0; u < R; ++u)
       for (int reg = 0; reg < 4; ++reg) {
         const int n0 = (16 * u + 4 * g + reg) / R;
         double c, s;
         cexp(static_cast<long>(n0) * x, 256, c, s);
-        put_f(kOffS + u * 2048 + lane * 32 + 4 * reg, c / R);
-        put_f(kOffS + u * 2048 + lane * 32 + 16 + 4 * reg, s / R);
+        put_f(kOffS + u * 2048 + lane * 32 + 4 * reg, c * s_scale);
+        put_f(kOffS + u * 2048 + lane * 32 + 16 + 4 * reg, s * s_scale);
       }
     for (int r = 1; r < R; ++r)
       for (int reg = 0; reg < 4; ++reg) {
@@ -107,8 +110,8 @@ inline void build_tables(int R, std::vector<uint8_t>& blob) {
 // non-temporal 16-byte stores, instead of 8-byte pieces straight from registers.
 template <int R, bool STG = true>
 __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in_re, const uint16_t* in_im,
-                                                              uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
-                                                              uint64_t out_stride, uint32_t batch,
+                                                              uint16_t* out_re, uint16_t* out_im, Addr in_map,
+                                                              Addr out_map, uint32_t batch,
                                                               const uint8_t* __restrict__ tables) {
   constexpr int kPerWave = 16 / R;          // transforms per wave iteration
   constexpr int kPlane = 512 * R;           // bytes of one plane of one transform
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
       const int t = i / R, ii = i % R, plane = ii / (R / 2), pq = ii % (R / 2);
       // transforms past the end of the batch re-read the last valid one (their results are not stored)
       const uint32_t b = b0 + (static_cast<uint32_t>(t) < nb ? t : nb - 1);
-      const uint8_t* src = reinterpret_cast<const uint8_t*>((plane ? in_im : in_re) + static_cast<uint64_t>(b) * in_stride) +
+      const uint8_t* src = reinterpret_cast<const uint8_t*>((plane ? in_im : in_re) + in_map.off(b)) +
                            src_off[pq];
       const uint32_t d = wl_off + i * 1024;
       uint32_t keep;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
           *reinterpret_cast<u2*>(slot + kPlane + 512 * s) = u2{pk_im[s][0], pk_im[s][1]};
         }
       } else if (static_cast<uint32_t>(t) < nb) {
-        const uint64_t o = static_cast<uint64_t>(b0 + t) * out_stride + out_lane;
+        const uint64_t o = out_map.off(b0 + t) + out_lane;
 #pragma unroll
         for (int s = 0; s < R; ++s) {
           const u2 vr = {pk_re[s][0], pk_re[s][1]};
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
         const int t = i / R, ii = i % R, plane = ii / (R / 2), pq = ii % (R / 2);
         const u4 v = *reinterpret_cast<const u4*>(wl + i * 1024 + 16 * lane);
         if (static_cast<uint32_t>(t) < nb) {
-          uint16_t* dst = (plane ? out_im : out_re) + static_cast<uint64_t>(b0 + t) * out_stride + 512 * pq + 8 * lane;
+          uint16_t* dst = (plane ? out_im : out_re) + out_map.off(b0 + t) + 512 * pq + 8 * lane;
           __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
         }
       }

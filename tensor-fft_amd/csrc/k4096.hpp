@@ -78,10 +78,29 @@ typedef short s4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 
+// Where transform b of a batch starts inside a plane, in halves: (b >> gshift) * gstride + (b & gmask) * stride.
+// Plain batches: gshift = 0, gmask = 0, gstride = stride. Grouped: the 2^gshift rows of one outer entry are `stride`
+// apart and the outer entries `gstride` apart (row pass of a transposed-order plan: rows of a [N1][N2] matrix inside
+// each [RE | IM] block).
+struct Addr {
+  uint64_t stride, gstride;
+  uint32_t gshift, gmask;
+  __host__ __device__ uint64_t off(uint32_t b) const {
+    return static_cast<uint64_t>(b >> gshift) * gstride + static_cast<uint64_t>(b & gmask) * stride;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // host: constant operands
 // ---------------------------------------------------------------------------
-inline void build_tables(std::vector<uint8_t>& blob) {
+// Power-of-two factors folded into the constant operands (tfft_plan_opts.scale, include/tfft.h): f on the stage-1
+// matrix F (both slot orders), g on G, h on H, tw on the fp32 inter-stage twiddle block. Sequential scaling = 1/16 per
+// MFMA stage; unscaled = 1; the k4096r front end leaves a factor 1/2 of headroom that tw gives back (tw = 2).
+struct TableScale {
+  double f = 1.0 / 16, g = 1.0 / 16, h = 1.0 / 16, tw = 1.0;
+};
+
+inline void build_tables(std::vector<uint8_t>& blob, const TableScale ts = TableScale()) {
   blob.assign(kTableBytes, 0);
   auto put_h = [&](int off, double v) {
     const _Float16 h = static_cast<_Float16>(v);
@@ -103,8 +122,8 @@ inline void build_tables(std::vector<uint8_t>& blob) {
     for (int j = 0; j < 4; ++j) {
       double c, s;
       cexp(static_cast<long>(sigma(g, j)) * x, 16, c, s);
-      c /= 16.0;
-      s /= 16.0;
+      c *= ts.f;
+      s *= ts.f;
       const int base = kOffF1 + lane * 32;
       put_h(base + 2 * j, c);              // RE-form  [ C_re | -C_im ]
       put_h(base + 2 * (4 + j), -s);
@@ -114,8 +133,8 @@ inline void build_tables(std::vector<uint8_t>& blob) {
     for (int j = 0; j < 4; ++j) {          // natural slot order: contraction index 4g + j
       double c, s;
       cexp(static_cast<long>(4 * g + j) * x, 16, c, s);
-      c /= 16.0;
-      s /= 16.0;
+      c *= ts.f;
+      s *= ts.f;
       const int base = kOffF1n + lane * 32;
       put_h(base + 2 * j, c);
       put_h(base + 2 * (4 + j), -s);
@@ -126,19 +145,19 @@ inline void build_tables(std::vector<uint8_t>& blob) {
     for (int r = 0; r < 4; ++r) {
       double c, s;
       cexp(static_cast<long>(4 * g + r) * x, 256, c, s);
-      put_f(kOffTw + lane * 32 + 4 * r, c);
-      put_f(kOffTw + lane * 32 + 16 + 4 * r, s);
+      put_f(kOffTw + lane * 32 + 4 * r, c * ts.tw);
+      put_f(kOffTw + lane * 32 + 16 + 4 * r, s * ts.tw);
     }
     for (int k0 = 0; k0 < 16; ++k0)
       for (int j = 0; j < 4; ++j) {
         const int idx = 4 * g + j;   // contraction index n1 (G) or n0 (H)
         double c, s;
         cexp(static_cast<long>(idx) * (k0 + 16 * x), 256, c, s);      // G_k0[n1][k1 = x]
-        put_h(kOffG + k0 * 1024 + lane * 16 + 2 * j, c / 16.0);
-        put_h(kOffG + k0 * 1024 + lane * 16 + 2 * (4 + j), -s / 16.0);
+        put_h(kOffG + k0 * 1024 + lane * 16 + 2 * j, c * ts.g);
+        put_h(kOffG + k0 * 1024 + lane * 16 + 2 * (4 + j), -s * ts.g);
         cexp(static_cast<long>(idx) * (k0 + 256 * x), 4096, c, s);    // H_k0[n0][k2 = x]
-        put_h(kOffH + k0 * 1024 + lane * 16 + 2 * j, c / 16.0);
-        put_h(kOffH + k0 * 1024 + lane * 16 + 2 * (4 + j), -s / 16.0);
+        put_h(kOffH + k0 * 1024 + lane * 16 + 2 * j, c * ts.h);
+        put_h(kOffH + k0 * 1024 + lane * 16 + 2 * (4 + j), -s * ts.h);
       }
   }
 }
@@ -240,8 +259,8 @@ __device__ __forceinline__ void st(uint16_t* p, u4 v) {
 // in_*/out_*: planar binary16; FFT b at +b*stride halves. tables: build_tables() blob.
 template <int V>
 __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
-    const uint16_t* in_re, const uint16_t* in_im, uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
-    uint64_t out_stride, uint32_t batch, const uint8_t* __restrict__ tables) {
+    const uint16_t* in_re, const uint16_t* in_im, uint16_t* out_re, uint16_t* out_im, Addr in_map,
+    Addr out_map, uint32_t batch, const uint8_t* __restrict__ tables) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -268,8 +287,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
   if (b >= batch) return;
   // (Issuing this first copy ahead of the table fill was measured 9-20 % SLOWER: workgroups then start their HBM
   // reads in lock-step. profiles/r1_k4096_grid_scan.txt)
-  dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(b) * in_stride),
-           reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(b) * in_stride), wl_off, lane);
+  dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(b)),
+           reinterpret_cast<const uint8_t*>(in_im + in_map.off(b)), wl_off, lane);
 
   const uint8_t* const g_tab = lds + lane * 16;
   const uint8_t* const h_tab = lds + 16384 + lane * 16;
@@ -295,8 +314,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
     first = false;
 
     if (V & kNoCompute) {
-      uint16_t* const f_re = out_re + static_cast<uint64_t>(b) * out_stride;
-      uint16_t* const f_im = out_im + static_cast<uint64_t>(b) * out_stride;
+      uint16_t* const f_re = out_re + out_map.off(b);
+      uint16_t* const f_im = out_im + out_map.off(b);
       u4 vr[8], vi[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -306,8 +325,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const uint32_t nb0 = b + stride_b;
       if (nb0 < batch)
-        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(nb0) * in_stride),
-               reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(nb0) * in_stride), wl_off, lane);
+        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(nb0)),
+               reinterpret_cast<const uint8_t*>(in_im + in_map.off(nb0)), wl_off, lane);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         st<V>(f_re + 512 * i + 8 * lane, vr[i]);
@@ -347,8 +366,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       // below, but make it explicit) before the region is overwritten by the next transform
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (nb < batch)
-        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(nb) * in_stride),
-               reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(nb) * in_stride), wl_off, lane);
+        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(nb)),
+               reinterpret_cast<const uint8_t*>(in_im + in_map.off(nb)), wl_off, lane);
     }
 
     // ---- n1 high bits (register index a = t >> 1) <-> k0 high bits (lane group)
@@ -361,8 +380,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       }
     // now pr[2a + pp][r] holds, for tile k0 = 4a + r, slots n1 = 4g + 2pp + {0,1}.
 
-    uint16_t* const fft_re = out_re + static_cast<uint64_t>(b) * out_stride;
-    uint16_t* const fft_im = out_im + static_cast<uint64_t>(b) * out_stride;
+    uint16_t* const fft_re = out_re + out_map.off(b);
+    uint16_t* const fft_im = out_im + out_map.off(b);
 
     // ---- stages 2 and 3, tile by tile; 8 tiles fill one 16-byte output vector
     auto tile23 = [&](int k0, f4& o_re, f4& o_im) {
@@ -437,8 +456,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
     if (!(V & kPrefetch)) {
       if (V & kStageOut) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image read out before reuse
       if (nb < batch)
-        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(nb) * in_stride),
-               reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(nb) * in_stride), wl_off, lane);
+        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(nb)),
+               reinterpret_cast<const uint8_t*>(in_im + in_map.off(nb)), wl_off, lane);
     }
   }
 }

@@ -41,8 +41,8 @@ using namespace k4096;
 // workgroup iterations (images x 512) and the strides are per image.
 template <int R, bool ROWS = false>
 __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* in_re, const uint16_t* in_im,
-                                                               uint16_t* out_re, uint16_t* out_im, uint64_t in_stride,
-                                                               uint64_t out_stride, uint32_t batch,
+                                                               uint16_t* out_re, uint16_t* out_im, Addr in_map,
+                                                               Addr out_map, uint32_t batch,
                                                                const uint8_t* __restrict__ tables) {
   constexpr int kGroups = kWavesPerBlock / R;      // transforms per workgroup iteration
   constexpr int kN = 4096 * R;
@@ -56,9 +56,10 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(tables + kOffG)[i];
   const h8 f_re = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32);
   const h8 f_im = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32 + 16);
-  // (x 2: gives back the headroom factor of the front end after two averaging MFMA stages, exact in fp32)
-  const f4 tw_re = 2.0f * *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
-  const f4 tw_im = 2.0f * *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
+  // (the plan builds this block with a factor 2, k4096::TableScale::tw: it gives back the headroom factor of the front end
+  // after two averaging MFMA stages, exact in fp32)
+  const f4 tw_re = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
+  const f4 tw_im = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     const uint32_t b = live ? b_raw : batch - 1;
     const uint32_t r0 = it & 511;
     const uint64_t in_off = ROWS ? static_cast<uint64_t>(r0 + 512 * s) * 4096 : 4096ull * s;
-    dma_in<true>(reinterpret_cast<const uint8_t*>(in_re + static_cast<uint64_t>(b) * in_stride + in_off),
-                 reinterpret_cast<const uint8_t*>(in_im + static_cast<uint64_t>(b) * in_stride + in_off), wl_off, lane);
+    dma_in<true>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(b) + in_off),
+                 reinterpret_cast<const uint8_t*>(in_im + in_map.off(b) + in_off), wl_off, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // A: all R blocks of every group's transform are in LDS
 
@@ -246,8 +247,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     if (ROWS) {
       // the row spectrum leaves from this wave's own region (no other wave needs it): row 512 s + r0 of the image
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      uint16_t* const row_re = out_re + static_cast<uint64_t>(b) * out_stride + static_cast<uint64_t>(512 * s + r0) * 4096;
-      uint16_t* const row_im = out_im + static_cast<uint64_t>(b) * out_stride + static_cast<uint64_t>(512 * s + r0) * 4096;
+      uint16_t* const row_re = out_re + out_map.off(b) + static_cast<uint64_t>(512 * s + r0) * 4096;
+      uint16_t* const row_im = out_im + out_map.off(b) + static_cast<uint64_t>(512 * s + r0) * 4096;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const u4 vr = *reinterpret_cast<const u4*>(wl + 1024 * i + 16 * lane);
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     __builtin_amdgcn_s_barrier();            // C: the R spectra of every group are staged
 
     // ---- interleaved read-out: X[R kk + s'] ; this wave stores output halves [4096 s, 4096 (s + 1)) of both planes
-    uint16_t* const f_out_re = out_re + static_cast<uint64_t>(b) * out_stride + out_chunk;
-    uint16_t* const f_out_im = out_im + static_cast<uint64_t>(b) * out_stride + out_chunk;
+    uint16_t* const f_out_re = out_re + out_map.off(b) + out_chunk;
+    uint16_t* const f_out_im = out_im + out_map.off(b) + out_chunk;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t idx0 = out_chunk + 512u * i + 8u * lane;   // first output index of this lane's 16 bytes

@@ -187,6 +187,7 @@ struct PassArgs {
   uint32_t m_shift;      // log2(m_f)
   const float2* tw_lo;   // w_N^e, e < min(N, 8192)
   const float2* tw_hi;   // w_N^(e * 8192), e < N / 8192 (unused when N <= 8192)
+  float scale;           // factor on the butterfly output: 1/R (sequential scaling), 1, or 1/N on the last pass (include/tfft.h)
 };
 
 template <int R>
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void pass_kernel(PassArgs a) {
     for (int i = 1; i < R; ++i) v[i] = cmul(v[i], w[i]);
   }
   dft<R>(v);
-  const float sc = 1.0f / R;
+  const float sc = a.scale;
   _Float16* yr = a.out_re + fft * a.out_stride + (j - k) * R + k;
   _Float16* yi = a.out_im + fft * a.out_stride + (j - k) * R + k;
   if (a.ns == 1) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void pass_pair_kernel(PassArgs a) {
   }
   dft<R>(v0);
   dft<R>(v1);
-  const float sc = 1.0f / R;
+  const float sc = a.scale;
   _Float16* yr = a.out_re + fft * a.out_stride + (j - k) * R + k;
   _Float16* yi = a.out_im + fft * a.out_stride + (j - k) * R + k;
 #pragma unroll

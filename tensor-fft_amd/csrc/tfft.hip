@@ -12,8 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "k4096.hpp"
@@ -48,6 +50,44 @@ inline int ilog2(uint64_t x) {
   return l;
 }
 
+// ---- tfft_plan_opts.variant: which bits exist (include/tfft.h). The debugging aids give WRONG or partial results and
+// are refused unless TFFT_DEBUG_VARIANTS=1 is set in the environment of the process that creates the plan.
+constexpr int kVarK4096 = 1 | 2 | 8 | 16;
+constexpr int kVarDebug = 4 | 64 | 128 | 65536 | (15 << 8);
+constexpr int kVarTuner = kVarK4096 | 32 | 4096 | 8192 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 |
+                          8388608 | 16777216 | 67108864;
+inline bool debug_variants_enabled() {
+  const char* e = std::getenv("TFFT_DEBUG_VARIANTS");
+  return e && e[0] == '1' && e[1] == 0;
+}
+
+// Opt-in to more than 64 KiB of dynamic LDS, once per (kernel, device). The outcome is STICKY: a failure is returned on
+// every later call too (a std::call_once would report it once and then launch without the attribute). Plans run this
+// for every kernel they can launch at creation time (prepare mode below), so tfft_exec stays a pure launch, also under
+// stream capture; the call here then only finds its map entry.
+int lds_opt_in(const void* fn, int device, int bytes) {
+  static std::mutex m;
+  static std::map<std::pair<const void*, int>, hipError_t> done;
+  hipError_t e;
+  {
+    std::lock_guard<std::mutex> lock(m);
+    const auto key = std::make_pair(fn, device);
+    auto it = done.find(key);
+    if (it == done.end()) it = done.emplace(key, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)).first;
+    e = it->second;
+  }
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  return TFFT_OK;
+}
+// prepare mode: walk the launch logic of a plan, run lds_opt_in for every kernel it selects, launch nothing
+thread_local bool g_prepare = false;
+#define TFFT_LAUNCH(kernel, grid, block, lds, stream, ...)                                        \
+  do {                                                                                            \
+    const int rc_ = lds_opt_in(reinterpret_cast<const void*>(kernel), p->device, (lds));          \
+    if (rc_) return rc_;                                                                          \
+    if (!g_prepare) hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);             \
+  } while (0)
+
 enum class PassKind { K4096, K4096R, K256, K256R, Col256, Stockham };
 
 struct Pass {
@@ -57,6 +97,18 @@ struct Pass {
   bool tw_next;       // Col256: apply the next pass's input twiddles to the output
   bool skip_tw;       // Stockham: input twiddles were applied by the previous pass
   int next_radix;     // radix of the following pass (Col256 with tw_next)
+  // tfft_plan_opts.scale bookkeeping (apply_scale_mode): factor on the butterfly output (Stockham), on the fp32 radix-2
+  // combine (radix-512 column pass), and on the twiddles a column pass applies
+  float scale = 1.0f;
+  float tw_scale = 1.0f;
+};
+
+// what the public tfft_plan_opts cannot say: knobs of the plans that other plans are built from
+struct InternalOpts {
+  uint32_t group_shift = 0;              // grouped batch addressing of a single-kernel plan (k4096::Addr)
+  uint64_t in_gstride = 0, out_gstride = 0;
+  int once_log2 = -1;                    // TFFT_SCALE_ONCE: exponent of the single factor (default log2 n)
+  bool rows2d = false;                   // tables for the fused 2D row pass (k4096r front end in front of the 4096 kernel)
 };
 
 }  // namespace
@@ -72,6 +124,15 @@ struct tfft_plan {
   uint32_t out_row_shift = 0, out_sub_shift = 0;
   uint64_t out_sub_stride = 0;
   std::vector<Pass> passes;
+  int scale_mode = TFFT_SCALE_SEQUENTIAL;
+  // four-step twiddle of a single column pass (tfft_plan_opts.fourstep_n): w_M^(k (col0 + c)); the w tables below are
+  // then built for M instead of n
+  uint64_t tw4_modulus = 0, tw4_col0 = 0;
+  k4096::Addr in_map{}, out_map{};       // single-kernel plans: where transform b starts (plain or grouped)
+  // TFFT_ORDER_TRANSPOSED: strided radix-N1 column pass (with the four-step twiddle) into the workspace, then N1 * batch
+  // contiguous N2-point transforms out of it; this plan then only owns the two sub-plans and the workspace
+  tfft_plan* sub_col = nullptr;
+  tfft_plan* sub_row = nullptr;
   void* d_tables = nullptr;     // k4096::build_tables blob (K4096 and Col256 passes)
   float2* d_tw_lo = nullptr;    // w_n tables (Col256 and Stockham passes)
   float2* d_tw_hi = nullptr;
@@ -187,14 +248,7 @@ inline uint32_t pick_grid(uint64_t blocks_needed, int num_cus, uint32_t iters) {
 
 template <int V>
 int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                   uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
-  static std::once_flag once[16];   // per device: opt in to the full 160 KiB of LDS
-  hipError_t attr = hipSuccess;
-  std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k4096::fft4096_kernel<V>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, k4096::kLdsBytes);
-  });
-  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+                   k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   const uint32_t blocks_needed =
       static_cast<uint32_t>((p->batch + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
   // Workgroups are sized so that each wave runs about two transforms: the second one's HBM->LDS copy flies under
@@ -204,7 +258,7 @@ int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, voi
   static const uint32_t iters_env = env_iters("TFFT_K4096_ITERS", 0);   // experiment knob
   const uint32_t iters = iters_env ? iters_env : (blocks_needed >= 4u * static_cast<uint32_t>(p->num_cus) ? 2u : 1u);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
-  hipLaunchKernelGGL(k4096::fft4096_kernel<V>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+  TFFT_LAUNCH(k4096::fft4096_kernel<V>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
                      static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
@@ -212,19 +266,12 @@ int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, voi
 }
 
 int launch_k256(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
-  static std::once_flag once[16];
-  hipError_t attr = hipSuccess;
-  std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k256::fft256_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, k256::kLdsBytes);
-  });
-  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+                k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   const uint64_t groups = (p->batch + k256::kFftsPerWave - 1) / k256::kFftsPerWave;
   const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
   static const uint32_t iters = env_iters("TFFT_K256_ITERS", 2);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
-  hipLaunchKernelGGL(k256::fft256_kernel, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
+  TFFT_LAUNCH(k256::fft256_kernel, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
                      static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
@@ -233,19 +280,12 @@ int launch_k256(const tfft_plan* p, const void* in_re, const void* in_im, void* 
 
 template <int R, bool STG>
 int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                   uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
-  static std::once_flag once[16];
-  hipError_t attr = hipSuccess;
-  std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k256r::fft256r_kernel<R, STG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, k256r::lds_bytes<R>());
-  });
-  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+                   k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   const uint64_t groups = (p->batch + (16 / R) - 1) / (16 / R);
   const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
   static const uint32_t iters = env_iters("TFFT_K256_ITERS", 2);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
-  hipLaunchKernelGGL((k256r::fft256r_kernel<R, STG>), dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
+  TFFT_LAUNCH((k256r::fft256r_kernel<R, STG>), dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
                      static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
@@ -253,7 +293,7 @@ int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, voi
 }
 
 int launch_k256r(const tfft_plan* p, int radix, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                 uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
+                 k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   const bool direct = p->variant & 1048576;   // 8-byte stores straight from registers instead of staged full rows
   switch (radix) {
     case 2:
@@ -270,21 +310,14 @@ int launch_k256r(const tfft_plan* p, int radix, const void* in_re, const void* i
 
 template <int R>
 int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                    uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
-  static std::once_flag once[16];
-  hipError_t attr = hipSuccess;
-  std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k4096r::fft4096r_kernel<R>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, k4096::kLdsBytes);
-  });
-  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
+                    k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   const uint32_t per_wg = k4096::kWavesPerBlock / R;      // transforms per workgroup iteration
   const uint32_t blocks_needed = static_cast<uint32_t>((p->batch + per_wg - 1) / per_wg);
   // persistent workgroups: with four workgroup barriers per transform the short-lived launch shape of the 4096
   // kernel does not help here (measured at 2^13: 405 / 425 / 440 / 457 Gsamples/s for 1 / 2 / 4 / all iterations)
   static const uint32_t iters = env_iters("TFFT_K4096R_ITERS", 1000000);   // experiment knob
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
-  hipLaunchKernelGGL(k4096r::fft4096r_kernel<R>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+  TFFT_LAUNCH(k4096r::fft4096r_kernel<R>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
                      static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
@@ -292,7 +325,7 @@ int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, vo
 }
 
 int launch_k4096r(const tfft_plan* p, int radix, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                  uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
+                  k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   switch (radix) {
     case 2: return launch_k4096r_t<2>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
     case 4: return launch_k4096r_t<4>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s);
@@ -303,24 +336,17 @@ int launch_k4096r(const tfft_plan* p, int radix, const void* in_re, const void* 
 // first pass of the fused 2D plan: iterations = images * 512 (k4096r.hpp, ROWS); p only lends its device and tables
 int launch_rows2d(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                   uint64_t image_stride, uint32_t iterations, hipStream_t s) {
-  static std::once_flag once[16];
-  hipError_t attr = hipSuccess;
-  std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k4096r::fft4096r_kernel<8, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, k4096::kLdsBytes);
-  });
-  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint32_t grid = std::min<uint32_t>(iterations, static_cast<uint32_t>(p->num_cus));
-  hipLaunchKernelGGL((k4096r::fft4096r_kernel<8, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+  TFFT_LAUNCH((k4096r::fft4096r_kernel<8, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
-                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), image_stride, image_stride,
-                     iterations, static_cast<const uint8_t*>(p->d_tables));
-  TFFT_HIP(hipGetLastError());
+                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), k4096::Addr{image_stride, image_stride, 0, 0},
+                     k4096::Addr{image_stride, image_stride, 0, 0}, iterations, static_cast<const uint8_t*>(p->d_tables));
+  if (!g_prepare) TFFT_HIP(hipGetLastError());
   return TFFT_OK;
 }
 
 int launch_k4096(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
-                 uint64_t in_stride, uint64_t out_stride, hipStream_t s) {
+                 k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   // opts.variant: 0 = default (staged, coalesced, non-temporal stores: the fastest measured on MI355X);
   // otherwise a mask of k4096::kPrefetch / kStageOut / kFakeStore / kNonTemporal, with 16 = "none of them".
   const int v = p->variant == 0 ? (k4096::kStageOut | k4096::kNonTemporal) : (p->variant & (15 | 64));
@@ -338,40 +364,26 @@ struct Planes {
   uint64_t stride;
 };
 
-template <int MODE, bool TW, bool STAGE, bool LUT>
+template <int MODE, int TW, bool STAGE, bool LUT>
 int launch_col_t(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
-  static std::once_flag once[16];
-  hipError_t attr = hipSuccess;
-  std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_kernel<MODE, TW, STAGE, LUT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kLdsBytes);
-  });
-  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint32_t blocks_needed = (a.tasks + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock;
   static const uint32_t iters = env_iters("TFFT_COL_ITERS", 1000000);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
-  hipLaunchKernelGGL((colfft::colfft256_kernel<MODE, TW, STAGE, LUT>), dim3(grid), dim3(k4096::kThreads), colfft::kLdsBytes, s, a);
+  TFFT_LAUNCH((colfft::colfft256_kernel<MODE, TW, STAGE, LUT>), dim3(grid), dim3(k4096::kThreads), colfft::kLdsBytes, s, a);
   return TFFT_OK;
 }
 
-template <int MODE, bool TW, bool NT, int W, bool STG = false>
+template <int MODE, int TW, bool NT, int W, bool STG = false>
 int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   using G = colfft::WgGeom<W>;
-  static std::once_flag once[16];
-  hipError_t attr = hipSuccess;
-  std::call_once(once[p->device & 15], [&] {
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds);
-  });
-  if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
   const uint64_t blocks = (a.tasks / a.groups) * a.pitch / G::kCols;
   static const uint32_t iters = env_iters("TFFT_COLWG_ITERS", 1000000);
   const uint32_t grid = pick_grid(blocks, p->num_cus * (8 / W), iters);
-  hipLaunchKernelGGL((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid), dim3(G::kThreadsW), G::kLds, s, a);
+  TFFT_LAUNCH((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid), dim3(G::kThreadsW), G::kLds, s, a);
   return TFFT_OK;
 }
 
-template <int MODE, bool TW, int W>
+template <int MODE, int TW, int W>
 int launch_col_wg_nt(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   // non-temporal copy-in and row stores (default; variant bit 262144 turns them off)
   if (MODE == colfft::kColsOnLanes && !(p->variant & 1048576))   // staged full-row stores (bit 1048576: direct 16-byte pieces)
@@ -381,20 +393,21 @@ int launch_col_wg_nt(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
 
 template <int W>
 int launch_col_wg_w(const tfft_plan* p, const Pass& ps, const colfft::Args& a, hipStream_t s) {
+  if (p->tw4_modulus) return launch_col_wg_nt<colfft::kColsInRegs, colfft::kTwFourStep, W>(p, a, s);
   if (a.ns_f == 1)
-    return ps.tw_next ? launch_col_wg_nt<colfft::kColsOnLanes, true, W>(p, a, s)
-                      : launch_col_wg_nt<colfft::kColsOnLanes, false, W>(p, a, s);
-  return ps.tw_next ? launch_col_wg_nt<colfft::kColsInRegs, true, W>(p, a, s)
-                    : launch_col_wg_nt<colfft::kColsInRegs, false, W>(p, a, s);
+    return ps.tw_next ? launch_col_wg_nt<colfft::kColsOnLanes, colfft::kTwNext, W>(p, a, s)
+                      : launch_col_wg_nt<colfft::kColsOnLanes, colfft::kTwNone, W>(p, a, s);
+  return ps.tw_next ? launch_col_wg_nt<colfft::kColsInRegs, colfft::kTwNext, W>(p, a, s)
+                    : launch_col_wg_nt<colfft::kColsInRegs, colfft::kTwNone, W>(p, a, s);
 }
 
 template <bool STAGE, bool LUT>
 int launch_col_s(const tfft_plan* p, const Pass& ps, const colfft::Args& a, hipStream_t s) {
   const bool on_lanes = (a.ns_f == 1);
-  if (on_lanes) return ps.tw_next ? launch_col_t<colfft::kColsOnLanes, true, STAGE, LUT>(p, a, s)
-                                  : launch_col_t<colfft::kColsOnLanes, false, STAGE, false>(p, a, s);
-  return ps.tw_next ? launch_col_t<colfft::kColsInRegs, true, STAGE, LUT>(p, a, s)
-                    : launch_col_t<colfft::kColsInRegs, false, STAGE, false>(p, a, s);
+  if (on_lanes) return ps.tw_next ? launch_col_t<colfft::kColsOnLanes, colfft::kTwNext, STAGE, LUT>(p, a, s)
+                                  : launch_col_t<colfft::kColsOnLanes, colfft::kTwNone, STAGE, false>(p, a, s);
+  return ps.tw_next ? launch_col_t<colfft::kColsInRegs, colfft::kTwNext, STAGE, LUT>(p, a, s)
+                    : launch_col_t<colfft::kColsInRegs, colfft::kTwNone, STAGE, false>(p, a, s);
 }
 
 int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipStream_t s) {
@@ -416,7 +429,10 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   a.tw_lo = p->d_tw_lo;
   a.tw_hi = p->d_tw_hi;
   a.tables = static_cast<const uint8_t*>(p->d_tables);
-  a.n_mask = p->n - 1;
+  a.n_mask = (p->tw4_modulus ? p->tw4_modulus : p->n) - 1;
+  a.tw_scale = ps.tw_scale;
+  a.comb_scale = ps.scale;
+  a.tw4_col0 = p->tw4_col0;
   a.copy_only = (p->variant & 65536) ? 1u : 0u;
   a.out_row_shift = p->out_row_shift;
   a.out_sub_shift = p->out_sub_shift;
@@ -437,28 +453,20 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   if (radix == 512) {
     // plan creation only emits this pass where the geometry fits (pitch, and ns_f unless it is 1, multiples of 64)
     const bool on_lanes = (a.ns_f == 1);
-    const void* fn = on_lanes ? (ps.tw_next ? reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsOnLanes, true>)
-                                            : reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsOnLanes, false>))
-                              : (ps.tw_next ? reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsInRegs, true>)
-                                            : reinterpret_cast<const void*>(colfft::colfft512_wg_kernel<colfft::kColsInRegs, false>));
-    static std::once_flag once[4][16];   // per kernel form and device: opt in to the 144 KiB of LDS
-    hipError_t attr = hipSuccess;
-    std::call_once(once[(on_lanes ? 2 : 0) + (ps.tw_next ? 1 : 0)][p->device & 15], [&] {
-      attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, colfft::kWg512LdsBytes);
-    });
-    if (attr != hipSuccess) return hip_fail(attr, "hipFuncSetAttribute(LDS)");
     const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
     if (on_lanes) {
       if (ps.tw_next)
-        hipLaunchKernelGGL((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
       else
-        hipLaunchKernelGGL((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, false>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
     } else {
-      if (ps.tw_next)
-        hipLaunchKernelGGL((colfft::colfft512_wg_kernel<colfft::kColsInRegs, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+      if (p->tw4_modulus)
+        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwFourStep>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+      else if (ps.tw_next)
+        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
       else
-        hipLaunchKernelGGL((colfft::colfft512_wg_kernel<colfft::kColsInRegs, false>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
     }
     return TFFT_OK;
   }
@@ -510,6 +518,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
 template <int R>
 void launch_pass(const stockham::PassArgs& a, uint64_t batch, hipStream_t s) {
   const uint64_t grid = (a.m_f * batch + stockham::kBlock - 1) / stockham::kBlock;
+  if (g_prepare) return;
   hipLaunchKernelGGL(stockham::pass_kernel<R>, dim3(static_cast<uint32_t>(grid)), dim3(stockham::kBlock), 0,
                      s, a);
 }
@@ -517,6 +526,7 @@ void launch_pass(const stockham::PassArgs& a, uint64_t batch, hipStream_t s) {
 template <int R>
 void launch_pass_pair(const stockham::PassArgs& a, uint64_t batch, hipStream_t s) {
   const uint64_t grid = ((a.m_f / 2) * batch + stockham::kBlock - 1) / stockham::kBlock;
+  if (g_prepare) return;
   hipLaunchKernelGGL(stockham::pass_pair_kernel<R>, dim3(static_cast<uint32_t>(grid)), dim3(stockham::kBlock), 0,
                      s, a);
 }
@@ -540,6 +550,7 @@ void launch_stockham_pass(const tfft_plan* p, const Pass& ps, Planes src, Planes
   a.m_shift = static_cast<uint32_t>(ilog2(a.m_f));
   a.tw_lo = p->d_tw_lo;
   a.tw_hi = p->d_tw_hi;
+  a.scale = ps.scale;
   // pre-twiddled radix-2/4/8 pass with an even sub-transform length: two butterflies per thread, 4-byte accesses
   // (measured +5 % on the whole 2^17 transform; for radix 16 it is neutral in 1D and -6 % on the 2D column pass, so
   // those keep one butterfly per thread). variant bit 4194304 keeps the one-butterfly kernel.
@@ -575,18 +586,32 @@ int ensure_workspace(const tfft_plan* p) {
 
 int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                  hipStream_t s) {
+  if (p->sub_col) {
+    // TFFT_ORDER_TRANSPOSED: column pass in -> planar workspace, row pass workspace -> out (in place is fine: the input
+    // has been read completely before the row pass writes)
+    _Float16* w = nullptr;
+    if (!g_prepare) {
+      const int rc = ensure_workspace(p);
+      if (rc) return rc;
+      w = static_cast<_Float16*>(p->ws);
+    }
+    _Float16* const w_im = w + p->batch * p->n;
+    int rc = launch_chain(p->sub_col, in_re, in_im, w, w_im, s);
+    if (rc) return rc;
+    return launch_chain(p->sub_row, w, w_im, out_re, out_im, s);
+  }
   int np = static_cast<int>(p->passes.size());
   if ((p->variant >> 8) & 15) np = std::min(np, (p->variant >> 8) & 15);   // debugging aid: run only the first passes
   if (single_kernel(p)) {
     const PassKind kind = p->passes[0].kind;
     const int rc = kind == PassKind::K4096
-                       ? launch_k4096(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s)
+                       ? launch_k4096(p, in_re, in_im, out_re, out_im, p->in_map, p->out_map, s)
                    : kind == PassKind::K4096R
-                       ? launch_k4096r(p, p->passes[0].radix, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s)
+                       ? launch_k4096r(p, p->passes[0].radix, in_re, in_im, out_re, out_im, p->in_map, p->out_map, s)
                        : (kind == PassKind::K256
-                              ? launch_k256(p, in_re, in_im, out_re, out_im, p->in_stride, p->out_stride, s)
-                              : launch_k256r(p, p->passes[0].radix, in_re, in_im, out_re, out_im, p->in_stride,
-                                             p->out_stride, s));
+                              ? launch_k256(p, in_re, in_im, out_re, out_im, p->in_map, p->out_map, s)
+                              : launch_k256r(p, p->passes[0].radix, in_re, in_im, out_re, out_im, p->in_map,
+                                             p->out_map, s));
     if (rc) return rc;
     TFFT_HIP(hipGetLastError());
     return TFFT_OK;
@@ -603,7 +628,7 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
   const bool use_in_as_scratch = !p->preserve_input && !in_place && odd;
   Planes SCR = IN;
   Planes SRC = IN;
-  if (!use_in_as_scratch && (np > 1 || in_place)) {
+  if (!use_in_as_scratch && (np > 1 || in_place) && !g_prepare) {
     const int rc = ensure_workspace(p);
     if (rc) return rc;
     _Float16* w = static_cast<_Float16*>(p->ws);
@@ -631,7 +656,43 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
     }
     cur = dst;
   }
-  TFFT_HIP(hipGetLastError());
+  if (!g_prepare) TFFT_HIP(hipGetLastError());
+  return TFFT_OK;
+}
+
+// Runs the launch logic of a plan without launching: every kernel it can select gets its LDS opt-in now, so that a
+// failure surfaces from tfft_plan_create and tfft_exec makes no runtime call besides the launches.
+int prepare_kernels(const tfft_plan* p) {
+  uint8_t* const fake = reinterpret_cast<uint8_t*>(uintptr_t{1} << 20);     // never dereferenced
+  const uint64_t span = 4 * (p->batch * std::max(p->in_stride, p->out_stride) + p->n * p->inner);
+  g_prepare = true;
+  const int rc = launch_chain(p, fake, fake + span, fake + 2 * span, fake + 3 * span, nullptr);
+  g_prepare = false;
+  return rc;
+}
+
+// Element-exact test whether two planes (batch blocks of nf halves, `stride` halves apart) share a half.
+bool planes_overlap(const void* pa, uint64_t sa, const void* pb, uint64_t sb, uint64_t batch, uint64_t nf) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(pa), b = reinterpret_cast<uintptr_t>(pb);
+  const uintptr_t a_end = a + 2 * ((batch - 1) * sa + nf), b_end = b + 2 * ((batch - 1) * sb + nf);
+  if (a_end <= b || b_end <= a) return false;
+  if (batch == 1 || sa != sb) return true;            // different strides: conservative
+  const uint64_t d = static_cast<uint64_t>(a > b ? a - b : b - a) / 2 % sa;     // halves, modulo the common stride
+  return d < nf || sa - d < nf;
+}
+
+int check_variant(uint64_t n, uint64_t inner, int variant) {
+  if (variant < 0 || (variant & ~(kVarTuner | kVarDebug)))
+    return fail(TFFT_ERR_ARG, "unknown bits in tfft_plan_opts.variant (" + std::to_string(variant) + ")");
+  if ((variant & kVarDebug) && !debug_variants_enabled())
+    return fail(TFFT_ERR_ARG, "tfft_plan_opts.variant " + std::to_string(variant) +
+                                  " holds a timing / debugging bit that produces WRONG or partial results "
+                                  "(4, 64, 128, 65536, p << 8); set TFFT_DEBUG_VARIANTS=1 to allow it");
+  if (n == 4096 && inner <= 1 && !(variant & 32)) {
+    const int v = variant & 15;
+    if ((variant & 16) && v) return fail(TFFT_ERR_ARG, "variant bit 16 (plain N = 4096 kernel) excludes bits 1, 2, 8");
+    if ((v & 1) && (v & 2)) return fail(TFFT_ERR_ARG, "variant bits 1 (prefetch) and 2 (staged stores) of the N = 4096 kernel exclude each other");
+  }
   return TFFT_OK;
 }
 
@@ -715,7 +776,82 @@ int tfft_max_no_optin_shared_mem(int device_id) {
   return static_cast<int>(prop.sharedMemPerBlock);
 }
 
-int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts, tfft_plan** out) {
+}  // extern "C" (reopened below)
+
+namespace {
+
+// tfft_plan_opts.scale -> constant operands and per-pass factors (include/tfft.h, TFFT_SCALE_*). Sequential: 1/16 per
+// MFMA stage in F / G / H, 1/R per autosort pass, 1/2 in the radix-512 combine. None: all of them 1. Once: as none, and
+// the single factor 2^-once_log2 rides on the LAST fp32 multiply of the plan: the inter-stage twiddle block of a
+// single-kernel plan, the butterfly output of a final autosort pass, the combine of a final radix-512 pass, the
+// twiddles the pass in front of a final radix-256 column pass applies (or that pass's own four-step twiddle), and for
+// a lone radix-256 column pass, which has no fp32 multiply at all, the stage-2 matrix G (2^-8 keeps G's entries normal).
+int apply_scale_mode(tfft_plan* p, const InternalOpts& io, k4096::TableScale& ts, double& r_fa, double& r_fb, double& r_s) {
+  const bool seq = p->scale_mode == TFFT_SCALE_SEQUENTIAL;
+  const double s16 = seq ? 1.0 / 16 : 1.0;
+  const int once_log2 = io.once_log2 >= 0 ? io.once_log2 : ilog2(p->n);
+  const double fin = p->scale_mode == TFFT_SCALE_ONCE ? std::ldexp(1.0, -once_log2) : 1.0;
+  ts = k4096::TableScale{s16, s16, s16, 1.0};
+  r_fa = r_fb = s16;
+  r_s = 1.0;
+  if (io.rows2d) ts.tw = 2.0;                  // fused 2D row pass: the front end's headroom factor (k4096r.hpp)
+  if (single_kernel(p)) {
+    const Pass& ps = p->passes[0];
+    if (ps.kind == PassKind::K4096 || ps.kind == PassKind::K256) ts.tw *= fin;
+    if (ps.kind == PassKind::K4096R) ts.tw = (seq ? 2.0 : 2.0 * ps.radix) * fin;   // the front end keeps its 1 / (2 R)
+    if (ps.kind == PassKind::K256R) r_s = (seq ? 1.0 / ps.radix : 1.0) * fin;
+    return TFFT_OK;
+  }
+  for (Pass& ps : p->passes) {
+    ps.tw_scale = 1.0f;
+    if (ps.kind == PassKind::Stockham) ps.scale = seq ? 1.0f / ps.radix : 1.0f;
+    else ps.scale = seq ? 0.5f : 1.0f;         // radix-512 combine (unused by radix-256 passes)
+  }
+  if (fin != 1.0) {
+    Pass& last = p->passes.back();
+    const float f = static_cast<float>(fin);
+    if (last.kind == PassKind::Stockham || last.radix == 512) last.scale *= f;
+    else if (p->tw4_modulus) last.tw_scale = f;
+    else if (p->passes.size() >= 2) p->passes[p->passes.size() - 2].tw_scale = f;
+    else if (once_log2 <= 8) ts.g *= fin;
+    else return fail(TFFT_ERR_ARG, "TFFT_SCALE_ONCE: this plan has no fp32 multiply to carry the scaling step");
+  }
+  return TFFT_OK;
+}
+
+int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts, const InternalOpts& io, tfft_plan** out);
+
+int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
+  // N = N1 N2: column pass (n = N1 along the strided axis, N2 columns, four-step twiddle w_N^(k1 n2)) into the planar
+  // workspace [RE: batch x N | IM: batch x N], then batch * N1 contiguous N2-point transforms from it into `out`, where
+  // the N1 rows of one transform sit N2 apart inside the caller's block (grouped addressing).
+  const uint64_t n = p->n, n2 = tfft_plan_transposed_n2(n), n1 = n / n2;
+  if (p->batch * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "batch * N1 too large for one launch");
+  const int mode = p->scale_mode;
+  tfft_plan_opts co{};
+  co.in_batch_stride = p->in_stride;
+  co.out_batch_stride = n;
+  co.inner = n2;
+  co.preserve_input = 1;
+  co.variant = (p->variant & (262144 | 524288)) | (n1 == 512 ? 67108864 : 0);
+  co.scale = mode == TFFT_SCALE_SEQUENTIAL ? TFFT_SCALE_SEQUENTIAL : TFFT_SCALE_NONE;
+  co.fourstep_n = n;
+  int rc = create_plan(n1, p->batch, device_id, &co, InternalOpts{}, &p->sub_col);
+  if (rc) return rc;
+  tfft_plan_opts ro{};
+  ro.in_batch_stride = n2;
+  ro.out_batch_stride = n2;
+  ro.preserve_input = 1;
+  ro.scale = mode;
+  InternalOpts ri;
+  ri.group_shift = static_cast<uint32_t>(ilog2(n1));
+  ri.in_gstride = n;                       // planar workspace: row b at b * N2 either way
+  ri.out_gstride = p->out_stride;
+  ri.once_log2 = ilog2(n);
+  return create_plan(n2, p->batch * n1, device_id, &ro, ri, &p->sub_row);
+}
+
+int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts, const InternalOpts& io, tfft_plan** out) {
   g_err.clear();
   if (!out) return fail(TFFT_ERR_ARG, "null plan pointer");
   *out = nullptr;
@@ -729,7 +865,24 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
   const uint64_t out_stride = (opts && opts->out_batch_stride) ? opts->out_batch_stride : 2 * nf;
   if (nf >= 8 && ((in_stride % 8) || (out_stride % 8))) return fail(TFFT_ERR_ARG, "batch strides must be multiples of 8 halves (16 bytes)");
   if (in_stride < nf || out_stride < nf) return fail(TFFT_ERR_ARG, "batch stride smaller than the FFT length");
-  int rc = tfft_device_check(device_id);
+  const int scale_mode = opts ? opts->scale : 0;
+  if (scale_mode < TFFT_SCALE_SEQUENTIAL || scale_mode > TFFT_SCALE_ONCE) return fail(TFFT_ERR_ARG, "unknown tfft_plan_opts.scale");
+  const int order = opts ? opts->output_order : 0;
+  if (order != TFFT_ORDER_NATURAL && order != TFFT_ORDER_TRANSPOSED) return fail(TFFT_ERR_ARG, "unknown tfft_plan_opts.output_order");
+  const uint64_t tw4 = opts ? opts->fourstep_n : 0;
+  if (tw4) {
+    if (!is_pow2(tw4) || tw4 < n || (n != 256 && n != 512) || inner < 64)
+      return fail(TFFT_ERR_ARG, "fourstep_n: the four-step twiddle exists for n = 256 or 512 along a strided axis of inner >= 64 columns, "
+                                "with fourstep_n a power of two >= n");
+    if (order == TFFT_ORDER_TRANSPOSED) return fail(TFFT_ERR_ARG, "fourstep_n and TFFT_ORDER_TRANSPOSED exclude each other");
+  }
+  int pvariant = opts ? opts->variant : 0;
+  if (tw4 && n == 512) pvariant |= 67108864;    // one radix-512 pass
+  int rc = check_variant(n, inner, pvariant);
+  if (rc) return rc;
+  if (tw4 && (pvariant & (32 | 131072 | 4096 | 8192)))
+    return fail(TFFT_ERR_ARG, "fourstep_n needs the workgroup-cooperative column kernels (variant bits 32, 4096, 8192, 131072 exclude it)");
+  rc = tfft_device_check(device_id);
   if (rc) return rc;
   int prev = 0;
   TFFT_HIP(hipGetDevice(&prev));
@@ -742,25 +895,45 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
   p->in_stride = in_stride;
   p->out_stride = out_stride;
   p->preserve_input = opts && opts->preserve_input;
-  p->variant = opts ? opts->variant : 0;
+  p->variant = pvariant;
+  p->scale_mode = scale_mode;
+  p->tw4_modulus = tw4;
+  p->tw4_col0 = opts ? opts->fourstep_col0 : 0;
+  p->in_map = k4096::Addr{in_stride, io.group_shift ? io.in_gstride : in_stride, io.group_shift, (1u << io.group_shift) - 1u};
+  p->out_map = k4096::Addr{out_stride, io.group_shift ? io.out_gstride : out_stride, io.group_shift, (1u << io.group_shift) - 1u};
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device_id);
   p->num_cus = (e == hipSuccess) ? prop.multiProcessorCount : 256;
   auto bail = [&](int code) {
+    const std::string keep = g_err;
     tfft_plan_destroy(p);
     (void)hipSetDevice(prev);
+    g_err = keep;
     return code;
   };
+  if (order == TFFT_ORDER_TRANSPOSED && inner == 1 && tfft_plan_transposed_n2(n)) {
+    rc = create_transposed(p, opts, device_id);
+    if (rc) return bail(rc);
+    (void)hipSetDevice(prev);
+    *out = p;
+    return TFFT_OK;
+  }
   // ---- pass list (plan_passes: pure host logic, also behind tfft_plan_describe)
-  const int pvariant = opts ? opts->variant : 0;
   plan_passes(n, inner, pvariant, p->passes);
+  if (io.group_shift && !single_kernel(p)) return bail(fail(TFFT_ERR_ARG, "grouped addressing needs a single-kernel plan"));
+  if (tw4 && !(p->passes.size() == 1 && p->passes[0].kind == PassKind::Col256))
+    return bail(fail(TFFT_ERR_ARG, "fourstep_n: this (n, inner) does not plan as one column pass"));
+  k4096::TableScale ts;
+  double r_fa, r_fb, r_s;
+  rc = apply_scale_mode(p, io, ts, r_fa, r_fb, r_s);
+  if (rc) return bail(rc);
   bool need_tables = false;
   for (const Pass& ps : p->passes)
     need_tables = need_tables || ps.kind == PassKind::K4096 || ps.kind == PassKind::K256 || ps.kind == PassKind::K4096R ||
                   ps.kind == PassKind::Col256;
   if (p->passes.size() == 1 && p->passes[0].kind == PassKind::K256R) {
     std::vector<uint8_t> blob;
-    k256r::build_tables(p->passes[0].radix, blob);
+    k256r::build_tables(p->passes[0].radix, blob, r_fa, r_fb, r_s);
     e = hipMalloc(&p->d_tables, blob.size());
     if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(tables)"));
     e = hipMemcpy(p->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice);
@@ -768,22 +941,23 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
   }
   if (need_tables) {
     std::vector<uint8_t> blob;
-    k4096::build_tables(blob);
+    k4096::build_tables(blob, ts);
     e = hipMalloc(&p->d_tables, blob.size());
     if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(tables)"));
     e = hipMemcpy(p->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(tables)"));
   }
   if (!single_kernel(p)) {
-    const uint64_t lo_n = std::min<uint64_t>(n, stockham::kTwLoSize);
-    const uint64_t hi_n = n > stockham::kTwLoSize ? n / stockham::kTwLoSize : 0;
+    const uint64_t tn = tw4 ? tw4 : n;          // modulus of the w tables
+    const uint64_t lo_n = std::min<uint64_t>(tn, stockham::kTwLoSize);
+    const uint64_t hi_n = tn > stockham::kTwLoSize ? tn / stockham::kTwLoSize : 0;
     std::vector<float2> lo(lo_n), hi(hi_n);
     for (uint64_t t = 0; t < lo_n; ++t) {
-      const double a = -2.0 * M_PI * static_cast<double>(t) / static_cast<double>(n);
+      const double a = -2.0 * M_PI * static_cast<double>(t) / static_cast<double>(tn);
       lo[t] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
     }
     for (uint64_t t = 0; t < hi_n; ++t) {
-      const double a = -2.0 * M_PI * static_cast<double>(t) * stockham::kTwLoSize / static_cast<double>(n);
+      const double a = -2.0 * M_PI * static_cast<double>(t) * stockham::kTwLoSize / static_cast<double>(tn);
       hi[t] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
     }
     e = hipMalloc(reinterpret_cast<void**>(&p->d_tw_lo), lo_n * sizeof(float2));
@@ -800,13 +974,41 @@ int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_
     if (max_blocks > 0x7fffffffull) return bail(fail(TFFT_ERR_ARG, "batch * N too large for one launch"));
     if ((nf / 16) * batch > 0xffffffffull) return bail(fail(TFFT_ERR_ARG, "batch * N too large for one launch"));
   }
+  rc = prepare_kernels(p);
+  if (rc) return bail(rc);
   (void)hipSetDevice(prev);
   *out = p;
   return TFFT_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts, tfft_plan** out) {
+  return create_plan(n, batch, device_id, opts, InternalOpts{}, out);
+}
+
+uint64_t tfft_plan_transposed_n2(uint64_t n) {
+  if (!is_pow2(n)) return 0;
+  const int lg = ilog2(n);
+  if (lg < 16 || lg > 24) return 0;
+  // N1 = 256 (256-byte row segments in the column pass) unless N2 would then leave the single-kernel range or 4096 is
+  // reachable with N1 = 512 (the N = 4096 kernel is the fastest second pass)
+  const int lg2 = (lg == 21 || lg == 24) ? lg - 9 : lg - 8;
+  return uint64_t{1} << lg2;
+}
+
+int tfft_variant_check(uint64_t n, uint64_t inner, int variant) {
+  g_err.clear();
+  if (!is_pow2(n) || n < 2) return fail(TFFT_ERR_NOT_POW2, "Error! Input size has to be a power of 2!");
+  return check_variant(n, inner ? inner : 1, variant);
+}
+
 void tfft_plan_destroy(tfft_plan* p) {
   if (!p) return;
+  tfft_plan_destroy(p->sub_col);
+  tfft_plan_destroy(p->sub_row);
   if (p->d_tables) (void)hipFree(p->d_tables);
   if (p->d_tw_lo) (void)hipFree(p->d_tw_lo);
   if (p->d_tw_hi) (void)hipFree(p->d_tw_hi);
@@ -820,6 +1022,8 @@ int tfft_plan_describe(uint64_t n, uint64_t inner, int variant, char* buf, size_
   if (!is_pow2(n) || n < 2) return fail(TFFT_ERR_NOT_POW2, "Error! Input size has to be a power of 2!");
   if (inner == 0) inner = 1;
   if (!is_pow2(inner) || (inner > 1 && inner < 8)) return fail(TFFT_ERR_ARG, "inner (strided-axis batch) must be 1 or a power of two >= 8");
+  const int vrc = check_variant(n, inner, variant);
+  if (vrc) return vrc;
   std::vector<Pass> passes;
   plan_passes(n, inner, variant, passes);
   std::string out;
@@ -837,9 +1041,14 @@ int tfft_plan_describe(uint64_t n, uint64_t inner, int variant, char* buf, size_
 }
 
 // passes over the data (a narrow column pass with a ragged batch takes two launches for its one pass)
-int tfft_plan_num_launches(const tfft_plan* p) { return p ? static_cast<int>(p->passes.size()) : 0; }
+int tfft_plan_num_launches(const tfft_plan* p) {
+  if (!p) return 0;
+  if (p->sub_col) return tfft_plan_num_launches(p->sub_col) + tfft_plan_num_launches(p->sub_row);
+  return static_cast<int>(p->passes.size());
+}
 
 size_t tfft_plan_workspace_bytes(const tfft_plan* p) {
+  if (p && p->sub_col) return static_cast<size_t>(p->batch) * p->n * 4;   // planar intermediate [RE | IM]
   if (!p || p->passes.size() == 1) {
     // a single pass needs scratch only when asked to run in place
     if (!p || single_kernel(p)) return 0;
@@ -867,6 +1076,18 @@ int tfft_exec(const tfft_plan* p, const void* in_re, const void* in_im, void* ou
   if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im) | reinterpret_cast<uintptr_t>(out_re) |
        reinterpret_cast<uintptr_t>(out_im)) & align)
     return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
+  // Aliasing: exact in-place (out plane == in plane, same stride) or fully disjoint planes. Anything else (out_re on
+  // in_im, shifted or partially overlapping blocks) would be read after it has been overwritten by another workgroup
+  // or by an earlier pass of the chain.
+  const bool same_re = in_re == out_re, same_im = in_im == out_im;
+  if ((same_re || same_im) && p->in_stride != p->out_stride)
+    return fail(TFFT_ERR_ARG, "in-place execution needs equal input and output batch strides");
+  if ((!same_re && planes_overlap(in_re, p->in_stride, out_re, p->out_stride, p->batch, nf)) ||
+      (!same_im && planes_overlap(in_im, p->in_stride, out_im, p->out_stride, p->batch, nf)) ||
+      planes_overlap(in_re, p->in_stride, out_im, p->out_stride, p->batch, nf) ||
+      planes_overlap(in_im, p->in_stride, out_re, p->out_stride, p->batch, nf) ||
+      planes_overlap(out_re, p->out_stride, out_im, p->out_stride, p->batch, nf))
+    return fail(TFFT_ERR_ARG, "input and output planes overlap without being identical (only exact in-place or disjoint planes are supported)");
   int cur = 0;
   TFFT_HIP(hipGetDevice(&cur));
   if (cur != p->device) return fail(TFFT_ERR_ARG, "plan was created for another device than the current one");
@@ -905,7 +1126,9 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
   if (p->fused) {
     // pass 1 (k4096r.hpp, ROWS): radix-8 column butterfly over the rows r0 + 512 i, fused with the 4096-point row
     // transforms; it only needs the 4096 kernel's constant tables, which a (4096, 1) plan owns.
-    rc = tfft_plan_create(4096, 1, device_id, nullptr, &p->row);
+    InternalOpts rio;
+    rio.rows2d = true;
+    rc = create_plan(4096, 1, device_id, nullptr, rio, &p->row);
     if (rc == TFFT_OK) {
       // pass 2: one radix-512 column pass per block of 512 intermediate rows; block s of an image writes rows 8 k' + s
       tfft_plan_opts co{};
@@ -918,6 +1141,14 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
         p->col->out_row_shift = 3;
         p->col->out_sub_shift = 3;
         p->col->out_sub_stride = cols;
+        uint8_t* const fake = reinterpret_cast<uint8_t*>(uintptr_t{1} << 20);     // LDS opt-in of the fused row kernel now
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(device_id);
+        g_prepare = true;
+        rc = launch_rows2d(p->row, fake, fake, fake, fake, rows * cols, 512, nullptr);
+        g_prepare = false;
+        (void)hipSetDevice(prev);
       }
     }
   } else {
@@ -1015,6 +1246,9 @@ int tfft_plan2d_exec(const tfft_plan2d* p, const void* in_re, const void* in_im,
   _Float16* t_im = t_re + static_cast<size_t>(p->batch) * p->rows * p->cols;
   if (p->fused) {
     if (!in_re || !in_im || !out_re || !out_im) return fail(TFFT_ERR_ARG, "null data pointer");
+    if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im) | reinterpret_cast<uintptr_t>(out_re) |
+         reinterpret_cast<uintptr_t>(out_im)) & 15)
+      return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
     int cur = 0;
     TFFT_HIP(hipGetDevice(&cur));
     if (cur != p->device) return fail(TFFT_ERR_ARG, "plan was created for another device than the current one");
@@ -1091,6 +1325,7 @@ int tfft_interleave(const void* in_re, const void* in_im, void* out_half2, uint6
 
 const char* tfft_plan_kernel_name(const tfft_plan* p) {
   if (!p) return "";
+  if (p->sub_col) return tfft_plan_kernel_name(p->sub_col);
   switch (p->passes[0].kind) {
     case PassKind::K4096: return "fft4096_kernel";
     case PassKind::K256: return "fft256_kernel";
@@ -1109,6 +1344,7 @@ double tfft_plan_algorithmic_bytes(const tfft_plan* p) {
 
 double tfft_plan_mfma_flops(const tfft_plan* p) {
   if (!p) return 0.0;
+  if (p->sub_col) return tfft_plan_mfma_flops(p->sub_col) + tfft_plan_mfma_flops(p->sub_row);
   // one radix-16 MFMA stage = 16 tiles x 2 MFMA(16x16x32) x 16384 flop per 4096 samples = 128 flop/sample
   double stages = 0;
   for (const Pass& ps : p->passes)

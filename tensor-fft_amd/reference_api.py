@@ -79,7 +79,13 @@ def _create_plan_from_file(fft_length, tuner_results_file):
                 mode = Mode_256 if int(tok[1]) == 256 else Mode_4096
                 plan = CreatePlan(fft_length, mode, int(tok[2]), int(tok[3]), int(tok[4]))
                 if plan is not None and len(tok) >= 6:      # tools/tuner.py appends the tuned kernel variant
-                    plan._variant = int(tok[5])
+                    try:
+                        variant = int(tok[5])
+                        capi.variant_check(fft_length, 1, variant)     # unknown or WRONG-result bits: refuse the line
+                    except (ValueError, capi.TfftError) as e:
+                        print(f"Error! Tuner file holds an unusable kernel variant for this fft length: {e}")
+                        return None
+                    plan._variant = variant
                 return plan
     print("Error! Tuner file didnt contain requested fft length.")
     return None

@@ -165,3 +165,99 @@ def test_planner_pass_counts():
     with pytest.raises(tf.TfftError):
         tf.plan_describe(3000)
 
+
+
+# ---- tfft_plan_opts.variant: only documented, CORRECT-result values pass (a stale tuner file must not
+# ---- select a timing-only kernel silently)
+DEBUG_VARIANTS = [4, 64, 128, 65536, 1 << 8, 3 << 8, 15 << 8, 4 | 8, 64 | 8, 524288 | 128]
+TUNER_VARIANTS = [0, 1, 2, 8, 9, 10, 16, 32, 4096, 8192, 131072, 262144, 524288, 1048576, 2097152, 4194304, 8388608,
+                  16777216, 16777216 | 8388608]
+
+
+def test_variant_check_refuses_debug_and_unknown_bits(monkeypatch):
+    monkeypatch.delenv("TFFT_DEBUG_VARIANTS", raising=False)
+    for n in (256, 4096, 8192, 1 << 16, 1 << 20):
+        for v in TUNER_VARIANTS:
+            capi.variant_check(n, 1, v)
+        for v in DEBUG_VARIANTS:
+            with pytest.raises(tf.TfftError) as e:
+                capi.variant_check(n, 1, v)
+            assert e.value.code == 5 and "TFFT_DEBUG_VARIANTS" in e.value.message
+            with pytest.raises(tf.TfftError):
+                tf.plan_describe(n, 1, v)
+        for v in (1 << 27, 1 << 30, -1, 1 << 12 | 1 << 28):
+            with pytest.raises(tf.TfftError) as e:
+                capi.variant_check(n, 1, v)
+            assert "unknown" in e.value.message
+    for v in (3, 11, 16 | 2, 16 | 8):                       # N = 4096 kernel: combinations without a compiled kernel
+        with pytest.raises(tf.TfftError):
+            capi.variant_check(4096, 1, v)
+    monkeypatch.setenv("TFFT_DEBUG_VARIANTS", "1")          # the experiment drivers under tools/ set this
+    for v in DEBUG_VARIANTS:
+        capi.variant_check(1 << 20, 1, v)
+
+
+def test_tuner_file_with_unusable_variant_is_refused(tmp_path, capsys, monkeypatch):
+    monkeypatch.delenv("TFFT_DEBUG_VARIANTS", raising=False)
+    f = tmp_path / "TunerResults.dat"
+    f.write_text("4096 4096 16 1 256 64\n65536 4096 16 1 256 65536\n1048576 4096 16 1 256 524288\n"
+                 "262144 4096 16 1 256 notanumber\n131072 4096 16 1 256 134217728\n")
+    assert tf.CreatePlan(4096, str(f)) is None                      # 64 = no-compute timing kernel
+    assert tf.CreatePlan(65536, str(f)) is None                     # 65536 = copy-only column pass
+    assert tf.CreatePlan(262144, str(f)) is None
+    assert tf.CreatePlan(131072, str(f)) is None                    # unknown bit
+    assert "unusable kernel variant" in capsys.readouterr().out
+    assert tf.CreatePlan(1 << 20, str(f))._variant == 524288
+
+
+def test_every_committed_tuner_file_holds_only_accepted_variants(monkeypatch):
+    import glob
+
+    monkeypatch.delenv("TFFT_DEBUG_VARIANTS", raising=False)
+    files = glob.glob(os.path.join(ROOT, "profiles", "*TunerResults.dat"))
+    assert files
+    for path in files:
+        for line in open(path):
+            tok = line.split()
+            if len(tok) >= 6:
+                capi.variant_check(int(tok[0]), 1, int(tok[5]))
+
+
+def _hipcc_host(src, exe, *extra):
+    import subprocess
+
+    pkg = os.path.join(ROOT, "tensor-fft_amd")
+    subprocess.check_call(["hipcc", "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+                           "-o", exe, src, "-L", pkg, "-ltfft", "-Wl,-rpath," + pkg, *extra])
+
+
+def test_cxx_shim_tuner_file_overload_keeps_column_six(tmp_path, monkeypatch):
+    """include/tensor_fft.hpp CreatePlan(N, file): same plan as the Python binding from the same file, and
+    the same refusals. Host only: CreatePlan touches no device."""
+    import subprocess
+
+    monkeypatch.delenv("TFFT_DEBUG_VARIANTS", raising=False)
+    exe = str(tmp_path / "tuner_file_host")
+    _hipcc_host(os.path.join(ROOT, "tests", "cxx", "tuner_file_host.cpp"), exe)
+    f = tmp_path / "TunerResults.dat"
+    f.write_text("4096 4096 16 4 128 10\n8192 256 8 16 256\n65536 4096 16 1 256 65536\n1048576 4096 16 1 256 524288\n")
+
+    def run(n):
+        return subprocess.run([exe, str(f), str(n)], capture_output=True, text=True, check=True).stdout.split("\n")[-2].split()
+
+    assert run(4096) == ["ok", "10", "2", "0", "1"]
+    assert run(8192) == ["ok", "0", "2", "1", "0"]
+    assert run(1 << 20) == ["ok", "524288", "4", "0", "1"]
+    assert run(65536) == ["refused"]
+    assert run(1 << 22) == ["refused"]
+    for n in (4096, 8192, 1 << 20):
+        p = tf.CreatePlan(n, str(f))
+        assert [str(p._variant), str(p.amount_of_r16_steps_), str(p.amount_of_r2_steps_), str(p.base_fft_mode_)] == run(n)[1:]
+
+
+def test_reference_style_mains_compile_against_the_shim(tmp_path):
+    """A main() that makes the reference's calls in the reference's order (ExampleBatchFFT.cu:20-85, ExampleSingleFFT.cu)
+    builds against include/tensor_fft.hpp with hipcc. (Running it needs a GPU: tests/test_gpu_parity.py.)"""
+    for name in ("example_batch_fft", "example_single_fft"):
+        _hipcc_host(os.path.join(ROOT, "examples", name + ".cpp"), str(tmp_path / name))
+        assert os.path.getsize(tmp_path / name) > 0

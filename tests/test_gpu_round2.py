@@ -1,0 +1,462 @@
+"""Round-2 parity tests (need an MI355X: `-m gpu`), all through the C ABI:
+
+* HIP path vs the oracle's fp16 RESTATEMENT of the reference kernels (orc.ref_fft) with a stated ULP tolerance, on
+  uniform data and on the reference's benchmark signal, incl. the N = 256 / 4096 / 8192 golden fixtures;
+* BASELINE configs[3] (fused 2D 4096 x 4096 plan) against the CPU fp64 oracle, and the batch-64 full-size run;
+* every kernel variant tools/tuner.py can emit (and every variant in the committed tuner files) against the oracle;
+* WRONG-result debugging variants are refused; aliasing rules of tfft_exec;
+* scale modes (TFFT_SCALE_NONE / ONCE), transposed output order, the four-step twiddle of the column pass.
+
+Stated ULP tolerance (north_star: "matches the reference CUDA kernel within a stated fp16 ULP tolerance"): for every
+output element, |HIP - restatement| <= ULP_TOL fp16 ulps, the ulp taken at max(|restatement element|, rms of the
+spectrum's components). Both paths approximate the same DFT(x)/N; the restatement rounds its accumulators to fp16 after
+every MMA (Ampere HMMA model), the HIP path accumulates in fp32, so the distance is dominated by the restatement's own
+error (about 4 ulp at the spectrum's rms for white input)."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REL_L2_TOL = 1.5e-3
+ULP_TOL = 8.0
+
+
+@pytest.fixture(scope="module")
+def tf():
+    import __graft_entry__ as g
+
+    g.build()
+    import torch
+
+    assert torch.cuda.is_available()
+    import tensor_fft_amd as t
+
+    t.device_check(0)
+    return t
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    return t
+
+
+def _c(re, im):
+    return np.asarray(re, dtype=np.float64) + 1j * np.asarray(im, dtype=np.float64)
+
+
+def _run(tf, torch, re, im, **plan_kw):
+    batch, n = re.shape
+    host = np.stack([re, im], axis=1)
+    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda().reshape(-1)
+    out = torch.full_like(dev, float("nan"))
+    plan = tf.TfftPlan(n, batch, 0, **plan_kw)
+    plan.exec(dev, dev[n:], out, out[n:])
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(batch, 2, n)
+    return o[:, 0], o[:, 1]
+
+
+def ulp_distance(got_re, got_im, ref_re, ref_im):
+    """max over elements of |got - ref| in fp16 ulps at max(|ref element|, rms of the reference spectrum's components)."""
+    g = np.concatenate([np.asarray(got_re, np.float64).ravel(), np.asarray(got_im, np.float64).ravel()])
+    r = np.concatenate([np.asarray(ref_re, np.float64).ravel(), np.asarray(ref_im, np.float64).ravel()])
+    rms = np.sqrt(np.mean(r * r))
+    mag = np.maximum(np.abs(r), max(rms, 2.0 ** -14))
+    ulp = 2.0 ** (np.floor(np.log2(mag)) - 10)
+    return float((np.abs(g - r) / ulp).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 1. HIP vs restatement, stated ULP tolerance
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lg", [8, 12, 13, 16, 20])
+def test_ulp_distance_to_reference_restatement_uniform(tf, torch, orc, lg):
+    n = 1 << lg
+    batch = 4 if lg <= 16 else 1
+    rng = np.random.default_rng(900 + lg)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    gr, gi = _run(tf, torch, re, im)
+    for mode in ((orc.MODE_256,) if n < 4096 else (orc.MODE_256, orc.MODE_4096)):
+        rr, ri = orc.ref_fft(re, im, mode)
+        d = max(ulp_distance(gr[b], gi[b], rr[b], ri[b]) for b in range(batch))
+        print(f"N=2^{lg} mode {mode}: max distance HIP vs restatement = {d:.2f} fp16 ulp")
+        assert d <= ULP_TOL, (lg, mode, d)
+
+
+@pytest.mark.parametrize("lg", [8, 12, 13, 16, 20])
+def test_ulp_distance_to_reference_restatement_benchmark_signal(tf, torch, orc, lg):
+    """The reference's benchmark signal (Bench.h:84-87: 10 harmonics, weights seeds 42 / 4242)."""
+    n = 1 << lg
+    re, im = orc.sine_superposition(n, orc.random_weights(10, 42), orc.random_weights(10, 4242), 10)
+    gr, gi = _run(tf, torch, re[None, :], im[None, :])
+    for mode in ((orc.MODE_256,) if n < 4096 else (orc.MODE_256, orc.MODE_4096)):
+        rr, ri = orc.ref_fft(re, im, mode)
+        d = ulp_distance(gr[0], gi[0], rr[0], ri[0])
+        print(f"benchmark signal N=2^{lg} mode {mode}: {d:.2f} fp16 ulp")
+        assert d <= ULP_TOL, (lg, mode, d)
+
+
+@pytest.mark.parametrize("n,modes", [(256, (0,)), (4096, (0, 1)), (8192, (0, 1))])
+def test_golden_fixtures_all_lengths(tf, torch, orc, golden_dir, n, modes):
+    """tests/golden/bench_signal.npz holds the restatement's outputs for N = 256, 4096 and 8192 (both base modes); the
+    HIP path must sit within the stated ULP tolerance of every one of them, and the oracle must still reproduce them."""
+    g = np.load(os.path.join(golden_dir, "bench_signal.npz"))
+    re = g[f"in_re_{n}"].view(np.float16)[None, :]
+    im = g[f"in_im_{n}"].view(np.float16)[None, :]
+    gr, gi = _run(tf, torch, re, im)
+    for m in modes:
+        fr, fi = g[f"ref_re_{n}_mode{m}"].view(np.float16), g[f"ref_im_{n}_mode{m}"].view(np.float16)
+        rr, ri = orc.ref_fft(re, im, m)
+        assert np.array_equal(rr[0].view(np.uint16), fr.view(np.uint16)) and np.array_equal(ri[0].view(np.uint16), fi.view(np.uint16))
+        d = ulp_distance(gr[0], gi[0], fr, fi)
+        assert d <= ULP_TOL, (n, m, d)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 2. BASELINE configs[3]: fused 2D 4096 x 4096 plan against the CPU oracle; full batch 64
+# ---------------------------------------------------------------------------------------------------------------
+def _oracle_fft2(orc, re, im):
+    """fp64 DFT2(x) / (rows cols) of one fp16 image with the oracle's 1D transform: rows, then columns."""
+    rows, cols = re.shape
+    a_re, a_im = orc.dft64(re, im)                                  # row transforms (batch = rows), fp16 in
+    a = np.ascontiguousarray((a_re + 1j * a_im).T)                  # [cols][rows]
+    return orc.fft64_rows(a).T                                      # column transforms, fp64 in
+
+
+def test_2d_4096_fused_plan_against_cpu_oracle(tf, torch, orc):
+    n = 4096
+    rng = np.random.default_rng(4096)
+    re = rng.uniform(-1, 1, (n, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (n, n)).astype(np.float16)
+    d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
+    o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
+    plan = tf.TfftPlan2D(n, n, 1, 0)
+    assert plan.num_launches == 2                                    # the fused two-pass plan
+    plan.exec(d_re, d_im, o_re, o_im)
+    torch.cuda.synchronize()
+    got = _c(o_re.cpu().numpy(), o_im.cpu().numpy()).reshape(n, n)
+    exact = _oracle_fft2(orc, re, im)
+    # the oracle's row pass is checked against numpy on a few rows, so both axes of `exact` are pinned
+    chk = np.fft.fft(_c(re[:4], im[:4]), axis=1) / n
+    o4 = orc.dft64(re[:4], im[:4])
+    assert np.abs(_c(*o4) - chk).max() < 1e-12
+    rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+    assert rel <= REL_L2_TOL, rel
+    ulp = 2.0 ** (np.floor(np.log2(np.sqrt(np.mean(np.abs(exact) ** 2) / 2))) - 10)
+    assert np.abs(got - exact).max() <= 12 * ulp, np.abs(got - exact).max() / ulp
+    # closed form on top: the reference's signal along both axes (integer-frequency tones)
+    w_re, w_im = orc.random_weights(10, 42), orc.random_weights(10, 4242)
+    s_re, s_im = orc.sine_superposition(n, w_re, w_im, 10)
+    img = np.outer(s_re.astype(np.float64), np.ones(n))             # constant along x, tones along y
+    d_re.copy_(torch.from_numpy(img.astype(np.float16)).reshape(-1))
+    d_im.zero_()
+    plan.exec(d_re, d_im, o_re, o_im)
+    torch.cuda.synchronize()
+    got = _c(o_re.cpu().numpy(), o_im.cpu().numpy()).reshape(n, n)
+    col0 = np.zeros(n, complex)
+    for f in range(1, 10):                                           # sin tone a_f -> -i a_f / 2 at +f, +i a_f / 2 at -f
+        col0[f] += -0.5j * w_re[f]
+        col0[n - f] += 0.5j * w_re[f]
+    assert np.abs(got[:, 0] - col0).max() < 2e-3 and np.abs(got[:, 1:]).max() < 2e-3
+
+
+def test_2d_4096_full_batch_64(tf, torch, orc):
+    """configs[3] at full size: 64 images (4 GiB in + 4 GiB out + 4 GiB scratch). Replicated images give bit-identical
+    spectra on every workgroup; Parseval per image; one image against the CPU oracle (sampled rows of the spectrum)."""
+    n, batch = 4096, 64
+    gen = torch.Generator(device="cuda").manual_seed(64)
+    re = (torch.rand(batch, n, n, device="cuda", generator=gen) * 2 - 1).half()
+    im = (torch.rand(batch, n, n, device="cuda", generator=gen) * 2 - 1).half()
+    re[1::2] = re[0]
+    im[1::2] = im[0]
+    o_re, o_im = torch.empty_like(re), torch.empty_like(im)
+    plan = tf.TfftPlan2D(n, n, batch, 0)
+    plan.exec(re.reshape(-1), im.reshape(-1), o_re.reshape(-1), o_im.reshape(-1))
+    torch.cuda.synchronize()
+    assert bool((o_re[1::2] == o_re[1]).all()) and bool((o_im[1::2] == o_im[1]).all())
+    e_in = (re.float() ** 2 + im.float() ** 2).sum(dim=(1, 2)) / (n * n)
+    e_out = (o_re.float() ** 2 + o_im.float() ** 2).sum(dim=(1, 2))
+    assert float(((e_out - e_in).abs() / e_in).max()) < 5e-3
+    b = 62                                                           # a non-replicated image, late in the batch
+    exact = _oracle_fft2(orc, re[b].cpu().numpy(), im[b].cpu().numpy())
+    got = _c(o_re[b].cpu().numpy(), o_im[b].cpu().numpy())
+    assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 3. every variant the tuner can emit, against the oracle
+# ---------------------------------------------------------------------------------------------------------------
+def _tuner_cases():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("tuner", os.path.join(ROOT, "tools", "tuner.py"))
+    tuner = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tuner)
+    cases = set()
+    for lg in range(8, 25):
+        for v in tuner.candidates(1 << lg):
+            cases.add((lg, v))
+    for path in glob.glob(os.path.join(ROOT, "profiles", "*TunerResults.dat")):
+        for line in open(path):
+            tok = line.split()
+            if len(tok) >= 6 and int(tok[0]) <= (1 << 24):
+                cases.add((int(tok[0]).bit_length() - 1, int(tok[5])))
+    return sorted(cases)
+
+
+_TUNER_CACHE = {}
+
+
+def _tuner_reference(tf, torch, orc, lg):
+    """inputs, fp64 oracle spectrum and the default plan's error for length 2^lg (computed once per length)."""
+    if lg not in _TUNER_CACHE:
+        n = 1 << lg
+        batch = 3 if lg <= 20 else 1
+        rng = np.random.default_rng(lg * 131)
+        re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+        im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+        exact = _c(*orc.dft64(re, im))
+        dr, di = _run(tf, torch, re, im, preserve_input=True)
+        _TUNER_CACHE.clear()                                         # keep one length resident (2^24 is 256 MiB of fp64)
+        _TUNER_CACHE[lg] = (re, im, exact, np.abs(_c(dr, di) - exact).max())
+    return _TUNER_CACHE[lg]
+
+
+@pytest.mark.parametrize("lg,variant", _tuner_cases())
+def test_every_tuner_variant_against_oracle(tf, torch, orc, lg, variant):
+    """tools/tuner.py's candidate lists and every (N, variant) line of the committed tuner files: each must give the
+    spectrum of the default plan within tolerance of the oracle (524288, 2097152, 1048576, 8388608 and the
+    4096-kernel masks had no parity test)."""
+    re, im, exact, err_d = _tuner_reference(tf, torch, orc, lg)
+    gr, gi = _run(tf, torch, re, im, variant=variant, preserve_input=True)
+    got = _c(gr, gi)
+    assert np.isfinite(got).all()
+    rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+    assert rel <= REL_L2_TOL, (lg, variant, rel)
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(exact).max())) - 10)
+    err_v = np.abs(got - exact).max()
+    assert err_v <= 1.5 * err_d + ulp, (lg, variant, err_v, err_d)
+
+
+def test_debug_variants_are_refused_at_plan_creation(tf, monkeypatch):
+    monkeypatch.delenv("TFFT_DEBUG_VARIANTS", raising=False)
+    for n, v in ((4096, 64), (4096, 4), (1 << 16, 65536), (1 << 16, 128), (1 << 20, 1 << 8), (1 << 20, 2 << 8)):
+        with pytest.raises(tf.TfftError) as e:
+            tf.TfftPlan(n, 2, 0, variant=v)
+        assert "TFFT_DEBUG_VARIANTS" in e.value.message
+    with pytest.raises(tf.TfftError):
+        tf.TfftPlan(4096, 2, 0, variant=1 << 27)
+    monkeypatch.setenv("TFFT_DEBUG_VARIANTS", "1")
+    assert tf.TfftPlan(1 << 20, 2, 0, variant=1 << 8).num_launches == 3      # tools/pass_breakdown.py still works
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 4. aliasing rules of tfft_exec
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [4096, 1 << 16])
+def test_partial_aliasing_is_rejected(tf, torch, n):
+    batch = 3
+    plan = tf.TfftPlan(n, batch, 0)
+    buf = torch.zeros(batch * 2 * n + 4 * n, dtype=torch.float16, device="cuda")
+    other = torch.zeros_like(buf)
+    base = buf.data_ptr()
+    ok = [(base, base + 2 * n, other.data_ptr(), other.data_ptr() + 2 * n),       # disjoint
+          (base, base + 2 * n, base, base + 2 * n)]                                 # exact in place
+    for a in ok:
+        plan.exec_ptr(*a)
+    bad = [(base, base + 2 * n, base + 2 * n, base),                                # out_re on in_im (planes crossed)
+           (base, base + 2 * n, base + 16, base + 2 * n + 16),                      # shifted by 8 halves
+           (base, base + 2 * n, base + 4 * n, base + 6 * n),                        # shifted by one block: overlaps the next FFT
+           (base, base + 2 * n, other.data_ptr(), other.data_ptr() + n)]            # out_re overlaps out_im
+    for a in bad:
+        with pytest.raises(tf.TfftError) as e:
+            plan.exec_ptr(*a)
+        assert e.value.code == 5
+    torch.cuda.synchronize()
+    # in place with different strides cannot be exact
+    p2 = tf.TfftPlan(n, batch, 0, in_batch_stride=2 * n, out_batch_stride=2 * n + 64)
+    with pytest.raises(tf.TfftError):
+        p2.exec_ptr(base, base + 2 * n, base, base + 2 * n)
+    # interleaved [in | out] per transform (stride 4 N, out = in + 2 N) shares no element: accepted
+    p3 = tf.TfftPlan(n, batch, 0, in_batch_stride=4 * n, out_batch_stride=4 * n)
+    big = torch.zeros(batch * 4 * n, dtype=torch.float16, device="cuda")
+    p3.exec_ptr(big.data_ptr(), big.data_ptr() + 2 * n, big.data_ptr() + 4 * n, big.data_ptr() + 6 * n)
+    torch.cuda.synchronize()
+
+
+def test_2d_fused_plan_checks_alignment(tf, torch):
+    n = 4096
+    plan = tf.TfftPlan2D(n, n, 1, 0)
+    buf = torch.zeros(4 * n * n + 64, dtype=torch.float16, device="cuda")
+    plan.set_workspace(torch.empty(plan.workspace_bytes // 2, dtype=torch.float16, device="cuda"))
+    from tensor_fft_amd import capi
+
+    lib = capi.load_library()
+    rc = lib.tfft_plan2d_exec(plan._h, buf.data_ptr() + 2, buf.data_ptr() + 2 * n * n, buf.data_ptr() + 4 * n * n,
+                              buf.data_ptr() + 6 * n * n, 0)
+    assert rc == 5 and "aligned" in capi.last_error()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 5. scale modes (reference TensorFFT256.cu:163-177, Radix2.cu:56-65)
+# ---------------------------------------------------------------------------------------------------------------
+SCALE_CASES = [(64, 1, 0), (256, 1, 0), (1024, 1, 0), (4096, 1, 0), (8192, 1, 0), (32768, 1, 0), (8192, 1, 16777216),
+               (1 << 15, 1, 16777216), (1 << 16, 1, 0), (1 << 17, 1, 0), (1 << 18, 1, 0), (1 << 20, 1, 0), (1 << 21, 1, 0),
+               (256, 64, 0), (512, 64, 67108864), (4096, 128, 0), (1 << 16, 1, 32)]
+
+
+@pytest.mark.parametrize("n,inner,variant", SCALE_CASES)
+@pytest.mark.parametrize("scale", ["none", "once"])
+def test_scale_modes(tf, torch, orc, n, inner, variant, scale):
+    """NONE: out = DFT(x) = N x the oracle's DFT(x)/N. ONCE: out = DFT(x)/N with a single scaling step. Inputs are sized
+    so that N max|x| stays inside fp16 (the documented overflow bound of the unscaled stages)."""
+    batch = 2
+    amp = min(1.0, 16384.0 / n)
+    rng = np.random.default_rng(n + inner + len(scale))
+    re = (rng.uniform(-1, 1, (batch, n, inner)) * amp).astype(np.float16)
+    im = (rng.uniform(-1, 1, (batch, n, inner)) * amp).astype(np.float16)
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    out = torch.full_like(dev, float("nan"))
+    plan = tf.TfftPlan(n, batch, 0, inner=inner, variant=variant, scale=scale)
+    plan.exec(dev, dev[n * inner:], out, out[n * inner:])
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(batch, 2, n, inner)
+    cre = np.ascontiguousarray(re.transpose(0, 2, 1)).reshape(-1, n)
+    cim = np.ascontiguousarray(im.transpose(0, 2, 1)).reshape(-1, n)
+    exact = _c(*orc.dft64(cre, cim)) * (n if scale == "none" else 1)
+    got = _c(o[:, 0].transpose(0, 2, 1).reshape(-1, n), o[:, 1].transpose(0, 2, 1).reshape(-1, n))
+    assert np.isfinite(got).all()
+    rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+    assert rel <= REL_L2_TOL, (n, inner, scale, rel)
+
+
+@pytest.mark.parametrize("n", [256, 4096, 8192, 1 << 16, 1 << 20])
+def test_scale_modes_are_exact_powers_of_two_apart(tf, torch, n):
+    """Away from overflow and underflow the three modes produce the same significands: NONE == N x SEQUENTIAL and
+    ONCE == SEQUENTIAL, bit for bit (every scaling factor is a power of two). Input amplitude 1/4 with N max|x| <= 2^14
+    ... 2^18 would overflow, so the check uses a sparse spectrum: a few tones of small amplitude."""
+    batch = 2
+    t = np.arange(n)
+    x = np.zeros((batch, n), complex)
+    for b in range(batch):
+        for f, a in ((3, 0.25), (n // 2 - 1, 0.125), (n // 3, 0.0625 * (b + 1))):
+            x[b] += a * np.exp(2j * np.pi * ((f * t) % n) / n)
+    x *= 8.0 / n if n > 4096 else 1.0 / 256                           # N max|x| stays below 8 (or 16): no overflow in NONE
+    re, im = x.real.astype(np.float16), x.imag.astype(np.float16)
+    seq = _run(tf, torch, re, im)
+    non = _run(tf, torch, re, im, scale="none")
+    once = _run(tf, torch, re, im, scale="once")
+    s = _c(*seq)
+    big = np.abs(s) > 2.0 ** -13                                       # compare where SEQUENTIAL is not subnormal
+    assert big.sum() >= 3 * batch
+    assert np.array_equal((_c(*non))[big], (s * n)[big])
+    assert np.array_equal((_c(*once))[big], s[big])
+
+
+def test_unscaled_overflow_bound(tf, torch):
+    """NONE: a constant of amplitude a gives X[0] = N a exactly while N a <= 65504, inf beyond (documented bound)."""
+    n = 4096
+    re = np.full((2, n), 8.0, np.float16)
+    re[1] = 32.0                                                       # N a = 131072 > 65504
+    im = np.zeros_like(re)
+    gr, gi = _run(tf, torch, re, im, scale="none")
+    assert float(gr[0, 0]) == 32768.0 and np.abs(gr[0, 1:]).max() == 0
+    assert not np.isfinite(gr[1, 0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 6. transposed output order and the four-step twiddle
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lg", list(range(16, 25)))
+@pytest.mark.parametrize("scale", ["sequential", "none", "once"])
+def test_transposed_output_order(tf, torch, orc, lg, scale):
+    """out[k1 N2 + k2] = X[k1 + N1 k2] in two passes (column pass with the four-step twiddle + contiguous N2-point pass)."""
+    if scale != "sequential" and lg not in (16, 20, 21):
+        pytest.skip("scale modes of the transposed plan: three lengths")
+    n = 1 << lg
+    batch = 3 if lg <= 20 else 1
+    n2 = tf.transposed_n2(n)
+    n1 = n // n2
+    assert n2 and n1 in (256, 512)
+    amp = 1.0 if scale != "none" else 4096.0 / n
+    rng = np.random.default_rng(lg)
+    re = (rng.uniform(-1, 1, (batch, n)) * amp).astype(np.float16)
+    im = (rng.uniform(-1, 1, (batch, n)) * amp).astype(np.float16)
+    plan = tf.TfftPlan(n, batch, 0, output_order="transposed", scale=scale)
+    assert plan.num_launches == 2 and plan.workspace_bytes == batch * n * 4
+    gr, gi = _run(tf, torch, re, im, output_order="transposed", scale=scale)
+    exact = _c(*orc.dft64(re, im)) * (n if scale == "none" else 1)
+    want = exact.reshape(batch, n2, n1).transpose(0, 2, 1).reshape(batch, n)     # [k2][k1] -> [k1][k2]
+    got = _c(gr, gi)
+    assert np.isfinite(got).all()
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel <= REL_L2_TOL, (lg, rel)
+    if scale == "sequential":
+        # not worse than the natural-order plan on the same input, and exactly in place
+        nr, ni = _run(tf, torch, re, im)
+        err_t, err_n = np.abs(got - want).max(), np.abs(_c(nr, ni) - exact).max()
+        assert err_t <= 1.5 * err_n + 2.0 ** -11 * np.abs(exact).max()
+        dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+        plan.exec(dev, dev[n:], dev, dev[n:])
+        torch.cuda.synchronize()
+        o = dev.cpu().numpy().reshape(batch, 2, n)
+        assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16)) and np.array_equal(o[:, 1].view(np.uint16), gi.view(np.uint16))
+
+
+def test_transposed_order_falls_back_outside_its_range(tf, torch, orc):
+    for n in (4096, 1 << 15):
+        assert tf.transposed_n2(n) == 0
+        rng = np.random.default_rng(n)
+        re = rng.uniform(-1, 1, (2, n)).astype(np.float16)
+        im = rng.uniform(-1, 1, (2, n)).astype(np.float16)
+        a = _run(tf, torch, re, im, output_order="transposed")
+        b = _run(tf, torch, re, im)
+        assert np.array_equal(a[0].view(np.uint16), b[0].view(np.uint16))
+
+
+@pytest.mark.parametrize("n1,cols,m,col0", [(256, 64, 1 << 14, 0), (256, 256, 1 << 20, 4096 - 256), (256, 1024, 1 << 18, 0),
+                                            (512, 64, 1 << 15, 0), (512, 512, 1 << 22, 512 * 7), (256, 8192, 1 << 26, 8192 * 5)])
+def test_fourstep_twiddle_of_the_column_pass(tf, torch, n1, cols, m, col0):
+    """fourstep_n = M: column pass output row k, column c times w_M^(k (col0 + c)); the step a distributed transform
+    needs in front of its all-to-all (rank offset col0) and the transposed-order plan uses with col0 = 0."""
+    batch = 2
+    rng = np.random.default_rng(n1 + cols)
+    re = rng.uniform(-1, 1, (batch, n1, cols)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n1, cols)).astype(np.float16)
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    out = torch.full_like(dev, float("nan"))
+    plan = tf.TfftPlan(n1, batch, 0, inner=cols, fourstep_n=m, fourstep_col0=col0)
+    assert plan.num_launches == 1
+    plan.exec(dev, dev[n1 * cols:], out, out[n1 * cols:])
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(batch, 2, n1, cols)
+    got = _c(o[:, 0], o[:, 1])
+    k = np.arange(n1)[:, None].astype(np.int64)
+    c = (col0 + np.arange(cols))[None, :].astype(np.int64)
+    tw = np.exp(-2j * np.pi * ((k * c) % m) / m)
+    want = np.fft.fft(_c(re, im), axis=1) / n1 * tw[None]
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel <= REL_L2_TOL, rel
+    assert np.abs(got - want).max() < 12 * 2.0 ** -11 * np.abs(want).max()
+    with pytest.raises(tf.TfftError):
+        tf.TfftPlan(1024, batch, 0, inner=cols, fourstep_n=m)                # only n = 256 / 512
+    with pytest.raises(tf.TfftError):
+        tf.TfftPlan(n1, batch, 0, inner=16, fourstep_n=m)                    # needs >= 64 columns
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 7. reference-style C++ main (ExampleBatchFFT.cu call sequence) runs
+# ---------------------------------------------------------------------------------------------------------------
+def test_cxx_reference_style_batch_example_runs():
+    exe = os.path.join(ROOT, "examples", "example_batch_fft")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr

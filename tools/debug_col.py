@@ -2,6 +2,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
+os.environ.setdefault("TFFT_DEBUG_VARIANTS", "1")   # experiment driver: partial-chain variants allowed
 import __graft_entry__ as g
 g.build()
 import tensor_fft_amd as tf

@@ -1,0 +1,61 @@
+"""One named workload, a few back-to-back executions: the command rocprofv3 wraps when collecting kernel traces and
+PMC counters for a kernel other than the headline one (python3 tools/prof_workload.py NAME [reps]).
+
+    c1      BASELINE configs[1]   4096 x 65536                    (fft4096_kernel)
+    c2      BASELINE configs[2]   2^20 x 1024                     (colfft256_wg_kernel x2 + tail)
+    c2t     configs[2] with the transposed-output order (two passes)
+    c3      BASELINE configs[3]   2D 4096 x 4096 x 64             (fft4096r_kernel<8,true> + colfft512_wg_kernel)
+    n8192 / n16384 / n32768       2^28 samples                    (fft4096r_kernel<R>)
+    n65536, n262144, n2^26 ...    any "nLEN[:batch]"
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as g
+
+g.build()
+import tensor_fft_amd as tf
+
+name = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+
+
+def run1d(n, b, **kw):
+    x = ((torch.rand(b * 2 * n, device="cuda") * 2 - 1)).half()
+    y = torch.empty_like(x)
+    plan = tf.TfftPlan(n, b, 0, preserve_input=True, **kw)
+    ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+    if plan.workspace_bytes:
+        plan.set_workspace(ws)
+    for _ in range(reps):
+        plan.exec(x, x[n:], y, y[n:])
+    torch.cuda.synchronize()
+    print(f"{name}: N={n} batch={b} passes={plan.num_launches} x{reps}")
+
+
+if name == "c1":
+    run1d(4096, 65536)
+elif name == "c2":
+    run1d(1 << 20, 1024)
+elif name == "c2t":
+    run1d(1 << 20, 1024, output_order="transposed")
+elif name == "c3":
+    n, b = 4096, 64
+    re = ((torch.rand(b * n * n, device="cuda") * 2 - 1)).half()
+    im = ((torch.rand(b * n * n, device="cuda") * 2 - 1)).half()
+    o_re, o_im = torch.empty_like(re), torch.empty_like(im)
+    plan = tf.TfftPlan2D(n, n, b, 0)
+    for _ in range(reps):
+        plan.exec(re, im, o_re, o_im)
+    torch.cuda.synchronize()
+    print(f"{name}: 2D 4096x4096 x{b} passes={plan.num_launches} x{reps}")
+elif name.startswith("n"):
+    f = name[1:].split(":")
+    n = (1 << int(f[0][2:])) if f[0].startswith("2^") else int(f[0])
+    b = int(f[1]) if len(f) > 1 else max(1, (1 << 28) // n)
+    run1d(n, b)
+else:
+    raise SystemExit(f"unknown workload {name}")

@@ -19,6 +19,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def candidates(n):
+    """Kernel variants (tfft_plan_opts.variant) tried for length n. Every value here is a documented, CORRECT-result
+    variant (tests/test_gpu_round2.py runs each against the oracle); the timing-only debugging bits are not tuner input.
+    0 = library default (2|8 at N = 4096); 32 = plain autosort chain; 524288 = 4-wave cooperative column workgroups;
+    2097152 = unfused radix-16 + radix-2/4 tail; 1048576 = unstaged column stores; 16777216 = column plan instead of
+    the single-pass kernel (2^13..2^15); 8388608 = no radix-512 column passes."""
+    if n == 4096:
+        return [16, 2, 10, 8, 1]
+    if n < 8192:
+        return [0, 32]
+    if n <= 32768:
+        return [0, 16777216, 16777216 | 8388608, 32]
+    return [0, 32, 524288, 2097152, 1048576, 8388608]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="TunerResults.dat")
@@ -41,17 +56,7 @@ def main():
         batch = max(1, (1 << args.total_log2) // n)
         x = (torch.rand(batch * 2 * n, device="cuda") * 2 - 1).half()
         y = torch.empty_like(x)
-        # 0 = library default (10 at N = 4096); 32 = plain autosort chain; 524288 = 4-wave cooperative column
-        # workgroups; 2097152 = unfused radix-16 + radix-2/4 tail; 1048576 = unstaged column stores
-        # 16777216 = column plan instead of the single-pass kernel (2^13..2^15); 8388608 = no radix-512 column passes
-        if n == 4096:
-            cands = [16, 2, 10, 8, 1]
-        elif n < 8192:
-            cands = [0, 32]
-        elif n <= 32768:
-            cands = [0, 16777216, 16777216 | 8388608, 32]
-        else:
-            cands = [0, 32, 524288, 2097152, 1048576, 8388608]
+        cands = candidates(n)
         best = None
         for v in cands:
             try:
