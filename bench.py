@@ -5,16 +5,24 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one tfft_exec over one resident batch of 65536 transforms (2^28 complex samples, 1 GiB in +
-1 GiB out in HBM). With N GPUs every rank owns its own batch of the same size (the batch shards with no
-data-path collective: SURVEY 8e), so scaling is weak and `value` is the aggregate over all ranks.
+One "step" = one tfft_exec over one resident batch. At 1 GPU the batch is BASELINE configs[1]: 65536 transforms
+(2^28 complex samples, 1 GiB in + 1 GiB out in HBM). With N > 1 GPUs every rank owns 2^21 transforms, the per-GPU
+share of BASELINE configs[4a] (batch 2^24 sharded over 8 GPUs: 32 GiB in + 32 GiB out per GPU); the batch shards
+with no data-path collective, so scaling is weak and `value` is the aggregate over all ranks.
 
-Rank 0 prints ONE JSON line. `roofline` is the HBM roofline of the dominant kernel (algorithmic bytes =
-8 B per complex sample per launch: 4 read + 4 written) with the launch duration measured here
-by HIP events on the launch stream. `cpu_baseline` is the CPU oracle's fp64 FFT (oracle/, a port: the
-reference has no CPU path, its oracle is cuFFT on the GPU) timed on this host's cores on a bounded sample.
-At N=1 GPU a further object `other_configs` carries short measurements of the other BASELINE configs (2^20 x 1024,
-2D 4096^2 x 64, single 2^26) and neighbouring lengths, taken AFTER the timed region; they do not enter `value`.
+Input: uniform(-1, 1) binary16 from the library's counter-based hash generator (tfft_synth_uniform, seed 42; transform
+index = global index over all ranks), born in HBM. Because every element is a pure function of (seed, transform, plane,
+sample), the CPU oracle regenerates any transform of the batch: rank 0 checks sampled transforms of the timed output
+against the oracle's fp64 DFT/N, so a broken kernel cannot post a number.
+
+Rank 0 prints ONE JSON line. `roofline` is the HBM roofline of the dominant kernel (algorithmic bytes = 8 B per complex
+sample per launch: 4 read + 4 written) with the launch duration measured here by HIP events on the launch
+stream. `cpu_baseline` is the CPU oracle (oracle/, a port: the reference has no CPU path, its oracle is cuFFT on the GPU)
+timed on this host's cores on a bounded sample of the same input: fp64 radix-2 FFT/N over OpenMP (`value`) and on one
+thread, plus the fp64 naive DFT/N at N=256 (BASELINE configs[0]) and at N=4096 on a 64-transform sub-batch.
+At 1 GPU `other_configs` carries short measurements of the other BASELINE configs (2^20 x 1024 natural and transposed
+order, 2D 4096^2 x 64, single 2^26) and neighbouring lengths, taken AFTER the timed region, each with an oracle check of
+a sampled transform / image; they do not enter `value`.
 """
 import argparse
 import json
@@ -27,47 +35,134 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N = 4096
-BATCH = 65536
+BATCH = 65536                  # BASELINE configs[1], one GPU
+BATCH_MULTI = 1 << 21          # BASELINE configs[4a]: 2^24 transforms over 8 GPUs
+SEED = 42
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16 MFMA
+REL_L2_TOL = 1.5e-3            # the library's stated tolerance against the fp64 DFT/N (tests/test_gpu_parity.py)
+
+RAMP = 100          # untimed launches before the warmup steps (GPU clock ramp, ~35 ms); the cold figure is reported too
 
 
-RAMP = 100          # untimed launches before the warmup steps (GPU clock ramp, ~35 ms)
+def usable_cores(omp_threads):
+    """Threads the CPU baseline may really use: OpenMP's count capped by the scheduler affinity and by the cgroup CPU
+    quota (a GPU box hands a one-GPU job a share of its host cores; running 128 threads on a 16-core quota only
+    measures the throttling)."""
+    n = omp_threads
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            tok = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if tok[0] != "max":
+                    n = min(n, max(1, int(int(tok[0]) / int(tok[1]))))
+            else:
+                q = int(tok[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
 
 
-def cpu_baseline(seconds_target=12.0):
-    """fp64 radix-2 FFT/N of the oracle over OpenMP threads on a bounded sample of the same workload."""
+def cpu_baseline(seconds_target=8.0):
+    """The oracle on this host's cores, on a bounded sample of the benchmark's own input (transforms 0.. of the batch)."""
     import numpy as np
     from oracle import orc
 
-    threads = orc.num_threads()
-    rng = np.random.default_rng(0)
+    threads = usable_cores(orc.num_threads())
     probe = 64 * threads
-    re = rng.uniform(-1, 1, (probe, N)).astype(np.float16)
-    im = rng.uniform(-1, 1, (probe, N)).astype(np.float16)
-    orc.dft64(re[:threads], im[:threads])                       # warm
+    re, im = orc.synth_uniform(N, probe, 0, SEED)                # the first `probe` transforms of the GPU batch
+    out = (np.zeros((probe, N)), np.zeros((probe, N)))           # reused: the loop times transforms, not page faults
+    orc.dft64(re, im, threads=threads, out=out)                  # warm
+    reps = 0
     t0 = time.perf_counter()
-    orc.dft64(re, im)
-    rate = probe / (time.perf_counter() - t0)                    # FFTs / s
-    reps = max(1, int(rate * seconds_target / probe))           # bounded: about seconds_target of CPU work
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        orc.dft64(re, im)
-    dt = time.perf_counter() - t0
+    while True:                                                  # bounded: about seconds_target of CPU work
+        orc.dft64(re, im, threads=threads, out=out)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target:
+            break
     done = reps * probe
+    # one thread, same code
+    n1 = 256
+    out1 = (out[0][:n1], out[1][:n1])
+    t0 = time.perf_counter()
+    orc.dft64(re[:n1], im[:n1], threads=1, out=out1)
+    dt1 = time.perf_counter() - t0
+    # naive O(N^2) DFT: N = 4096 on a 64-transform sub-batch (all threads and one thread), N = 256 (configs[0])
+    t0 = time.perf_counter()
+    orc.dft64(re[:64], im[:64], algo=0, threads=threads)
+    dt_naive = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.dft64(re[:4], im[:4], algo=0, threads=1)
+    dt_naive1 = time.perf_counter() - t0
+    r256, i256 = orc.synth_uniform(256, 4096, 0, SEED)
+    t0 = time.perf_counter()
+    orc.dft64(r256, i256, algo=0, threads=threads)
+    dt_256 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.dft64(r256[:256], i256[:256], algo=0, threads=1)
+    dt_256_1 = time.perf_counter() - t0
     return {
         "value": done * N / dt / 1e9,
         "unit": "Gsamples/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{done} FFTs of N={N} ({done / BATCH:.2f} x the GPU batch of {BATCH}; the same {probe} random "
-                  f"transforms repeated), oracle fp64 radix-2 FFT/N, OpenMP over the batch, {dt:.1f} s",
+        "sample": f"{done} FFTs of N={N} ({done / BATCH:.2f} x the GPU batch of {BATCH}; transforms 0..{probe - 1} of the "
+                  f"benchmark input, repeated), oracle fp64 radix-2 FFT/N, OpenMP over the batch, {dt:.1f} s",
+        "single_thread": {"value": n1 * N / dt1 / 1e9, "unit": "Gsamples/s", "cores": 1,
+                          "sample": f"{n1} FFTs of N={N}, fp64 radix-2 FFT/N, {dt1:.2f} s"},
+        "naive_dft_n4096_x64": {"value": 64 * N / dt_naive / 1e9, "unit": "Gsamples/s", "cores": threads,
+                                "sample": f"64 transforms of N={N}, fp64 O(N^2) DFT/N, {dt_naive:.2f} s",
+                                "single_thread_value": 4 * N / dt_naive1 / 1e9},
+        "naive_dft_n256": {"value": 4096 * 256 / dt_256 / 1e9, "unit": "Gsamples/s", "cores": threads,
+                           "sample": f"BASELINE configs[0]: 4096 transforms of N=256, fp64 O(N^2) DFT/N, {dt_256:.3f} s",
+                           "single_thread_value": 256 * 256 / dt_256_1 / 1e9},
+        "note": "the reference has no CPU implementation of this path (its oracle is cuFFT Z2Z on the GPU); this is the "
+                "repo's own CPU oracle",
     }
 
 
-def other_configs(torch, tf, device):
+def _rel_l2(got, exact):
+    import numpy as np
+
+    return float(np.linalg.norm(got - exact) / np.linalg.norm(exact))
+
+
+def check_transforms(torch, orc, y, n, batch, ids, first_fft=0, seed=SEED, perm=None, scale=1.0):
+    """Sampled transforms of an output block ([fft RE | fft IM], stride 2 n) against the oracle's fp64 DFT/N of the
+    regenerated input. perm: index map of a transposed-order spectrum. Returns the worst rel-L2 error; raises beyond
+    the library's stated tolerance."""
+    import numpy as np
+
+    worst = 0.0
+    for b in ids:
+        re, im = orc.synth_uniform(n, 1, first_fft + b, seed)
+        e_re, e_im = orc.dft64(re, im)
+        exact = (e_re[0] + 1j * e_im[0]) * scale
+        o = y[b * 2 * n:(b + 1) * 2 * n].cpu().numpy().astype(np.float64)
+        got = o[:n] + 1j * o[n:]
+        if perm is not None:
+            exact = exact[perm]
+        worst = max(worst, _rel_l2(got, exact))
+    if not worst < REL_L2_TOL:
+        raise SystemExit(f"self-check failed: N={n} rel-L2 error {worst:.3e} vs the CPU oracle")
+    return worst
+
+
+def other_configs(torch, tf, orc, device):
     """Short measurements of the other BASELINE configs and neighbouring lengths on the same GPU, after the headline
-    timing (not part of `value`): Gsamples/s over 10 back-to-back executions each, inputs resident, workspace preset."""
+    timing (not part of `value`): Gsamples/s over 10 back-to-back executions each, inputs resident, workspace preset,
+    and an oracle check of a sampled transform (or image) of what was just computed."""
+    import numpy as np
+
     out = {}
 
     def timed(fn, reps=10):
@@ -82,35 +177,79 @@ def other_configs(torch, tf, device):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    for name, n, b in (("n256_x_1048576", 256, 1 << 20), ("n1024_x_262144", 1024, 1 << 18),
-                       ("n8192_x_32768", 8192, 1 << 15), ("n65536_x_4096", 1 << 16, 1 << 12),
-                       ("configs[2]_n2^20_x_1024", 1 << 20, 1024), ("n2^24_x_16", 1 << 24, 16),
-                       ("configs[4b]_single_gpu_n2^26_x_1", 1 << 26, 1)):
-        x = (torch.rand(b * 2 * n, device="cuda") * 2 - 1).to(torch.float16)
+    cases = (("n256_x_1048576", 256, 1 << 20, "natural"), ("n1024_x_262144", 1024, 1 << 18, "natural"),
+             ("n8192_x_32768", 8192, 1 << 15, "natural"), ("n65536_x_4096", 1 << 16, 1 << 12, "natural"),
+             ("configs[2]_n2^20_x_1024", 1 << 20, 1024, "natural"),
+             ("configs[2]_n2^20_x_1024_transposed_order", 1 << 20, 1024, "transposed"),
+             ("n2^24_x_16", 1 << 24, 16, "natural"), ("configs[4b]_single_gpu_n2^26_x_1", 1 << 26, 1, "natural"))
+    for name, n, b, order in cases:
+        x = torch.empty(b * 2 * n, dtype=torch.float16, device="cuda")
+        tf.synth_uniform(x, x[n:], n, b, seed=SEED + n)
         y = torch.empty_like(x)
-        plan = tf.TfftPlan(n, b, device, preserve_input=True)
+        plan = tf.TfftPlan(n, b, device, preserve_input=True, output_order=order)
         ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
         if plan.workspace_bytes:
             plan.set_workspace(ws)
         ms = timed(lambda: plan.exec(x, x[n:], y, y[n:]))
-        out[name] = {"gsamples_per_s": n * b / ms / 1e6, "ms": ms, "passes": plan.num_launches}
+        perm = None
+        if order == "transposed":
+            n2 = tf.transposed_n2(n)
+            perm = np.arange(n).reshape(n2, n // n2).T.reshape(-1)         # out[k1 n2 + k2] = X[k1 + n1 k2]
+        if n <= (1 << 24):
+            err = check_transforms(torch, orc, y, n, b, sorted({0, b - 1}), seed=SEED + n, perm=perm)
+            check = f"transforms 0 and {b - 1} vs the fp64 oracle: rel-L2 {err:.2e}"
+        else:
+            # 2^26: the full fp64 oracle transform takes ~30 s of host time; check Parseval and 4 bins computed directly
+            xs = x.float()
+            e_in = float((xs * xs).sum()) / n
+            ys = y.float()
+            e_out = float((ys * ys).sum())
+            if not abs(e_out - e_in) / e_in < 5e-3:
+                raise SystemExit(f"self-check failed: N=2^26 Parseval {e_out} vs {e_in}")
+            t = torch.arange(n, device="cuda", dtype=torch.float64)
+            zr, zi = x[:n].double(), x[n:2 * n].double()
+            worst = 0.0
+            for k in (1, 4097, n // 3, n - 5):
+                ph = -2.0 * np.pi * ((t * k) % n) / n
+                c, s = torch.cos(ph), torch.sin(ph)
+                er = float((zr * c - zi * s).sum()) / n
+                ei = float((zr * s + zi * c).sum()) / n
+                gr, gi = float(y[k]), float(y[n + k])
+                worst = max(worst, abs(gr - er), abs(gi - ei))
+            rms = (e_in / n / 2) ** 0.5
+            if not worst < 8 * 2.0 ** -11 * max(rms, 2.0 ** -14):
+                raise SystemExit(f"self-check failed: N=2^26 bins off by {worst:.3e} (spectrum rms {rms:.3e})")
+            check = f"Parseval + 4 bins against a direct fp64 DFT sum on the device: max |delta| {worst:.2e} (spectrum rms {rms:.2e})"
+        out[name] = {"gsamples_per_s": n * b / ms / 1e6, "ms": ms, "passes": plan.num_launches, "check": check}
         del plan, x, y, ws
         torch.cuda.empty_cache()
     rows = cols = 4096
     images = 64
-    x = (torch.rand(images * 2 * rows * cols, device="cuda") * 2 - 1).to(torch.float16)
+    half = images * rows * cols                      # fully planar: all RE images, then all IM images
+    x = torch.empty(2 * half, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x[:half], x[half:], rows * cols, images, batch_stride=rows * cols, seed=SEED + 2)
     y = torch.empty_like(x)
     plan2 = tf.TfftPlan2D(rows, cols, images, device)
-    half = images * rows * cols                      # fully planar: all RE images, then all IM images
     ms = timed(lambda: plan2.exec(x[:half], x[half:], y[:half], y[half:]), reps=5)
-    out["configs[3]_2d_4096x4096_x_64"] = {"gsamples_per_s": half / ms / 1e6, "ms": ms, "passes": plan2.num_launches}
+    b = images - 1
+    re, im = orc.synth_uniform(rows * cols, 1, b, SEED + 2)
+    a_re, a_im = orc.dft64(re.reshape(rows, cols), im.reshape(rows, cols))
+    exact = orc.fft64_rows(np.ascontiguousarray((a_re + 1j * a_im).T)).T
+    got = (y[b * rows * cols:(b + 1) * rows * cols].cpu().numpy().astype(np.float64)
+           + 1j * y[half + b * rows * cols:half + (b + 1) * rows * cols].cpu().numpy().astype(np.float64)).reshape(rows, cols)
+    err = _rel_l2(got, exact)
+    if not err < REL_L2_TOL:
+        raise SystemExit(f"self-check failed: 2D 4096x4096 rel-L2 error {err:.3e} vs the CPU oracle")
+    out["configs[3]_2d_4096x4096_x_64"] = {"gsamples_per_s": half / ms / 1e6, "ms": ms, "passes": plan2.num_launches,
+                                           "check": f"image {b} vs the fp64 oracle (rows, then columns): rel-L2 {err:.2e}"}
     return out
 
 
 def shard(rank, world, total):
     """Contiguous slice [lo, hi) of `total` independent transforms owned by `rank`: the whole multi-GPU story of
     the batched path (FFTs are independent, no data-path collective). bench.py itself runs weak
-    scaling (every rank a full BASELINE batch); this helper documents and tests the strong-scaling split."""
+    scaling (every rank the same per-GPU batch); this helper gives the strong-scaling split and is what places a
+    rank's transforms in the global index space of the input generator."""
     per = total // world
     extra = total % world
     lo = rank * per + min(rank, extra)
@@ -138,7 +277,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=BATCH, help="transforms per GPU (default: the BASELINE config)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="transforms per GPU (default: 65536 = BASELINE configs[1] at 1 GPU, 2^21 = the per-GPU share of "
+                         "configs[4a] at N > 1 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra measurements of the other BASELINE configs (reported under 'other_configs')")
@@ -163,16 +304,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL: barrier + max only
 
     tf.device_check(local_rank)
-    batch = args.batch
-    gen = torch.Generator(device="cuda").manual_seed(42 + rank)
-    # synthetic planar fp16, uniform(-1,1), DataBatchHandler layout [fft_i RE | fft_i IM], resident in HBM
+    batch = args.batch or (BATCH if world == 1 else BATCH_MULTI)
+    first_fft, _ = shard(rank, world, batch * world)          # this rank's slice of the global transform index space
+    # synthetic planar fp16, uniform(-1,1), DataBatchHandler layout [fft_i RE | fft_i IM], born in HBM
     x = torch.empty(batch * 2 * N, dtype=torch.float16, device="cuda")
-    chunk = 1 << 26
-    for s in range(0, x.numel(), chunk):
-        e = min(x.numel(), s + chunk)
-        x[s:e] = (torch.rand(e - s, device="cuda", generator=gen) * 2 - 1).to(torch.float16)
+    tf.synth_uniform(x, x[N:], N, batch, first_fft=first_fft, seed=SEED)
     y = torch.empty_like(x)
     plan = tf.TfftPlan(N, batch, local_rank, preserve_input=True)
+    torch.cuda.synchronize()
 
     def step():
         plan.exec(x, x[N:], y, y[N:])
@@ -187,9 +326,17 @@ def main():
             dist.all_reduce(token)
             torch.cuda.synchronize()
 
-    # The GPU leaves its idle clock state only after a few milliseconds of work (20 steps timed cold read 0.382 ms
-    # per step, steady state 0.354 ms): RAMP untimed launches first, reported in the JSON line, then the contract's
-    # W warmup steps and K timed steps.
+    # The GPU leaves its idle clock state only after a few milliseconds of work. The first K launches are timed as they
+    # are (`cold_ms_per_step`, reported, not `value`), then RAMP untimed launches, the contract's W warmup steps and
+    # the K timed steps.
+    fence()
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(args.steps):
+        step()
+    c1.record()
+    fence()
+    cold_ms = c0.elapsed_time(c1) / args.steps
     for _ in range(RAMP):
         step()
     fence()
@@ -206,9 +353,9 @@ def main():
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps            # launches are back to back on one stream
     if dist is not None:
-        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, kernel_ms, cold_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = float(t[0]), float(t[1])
+        wall, kernel_ms, cold_ms = float(t[0]), float(t[1]), float(t[2])
 
     # per-launch spread (SURVEY 8d asks for mean and sigma; the true mean, not the reference's sum / (n - 1),
     # BenchUtil.h:41-48): 20 individually timed launches after the timed region, not part of `value`
@@ -223,7 +370,8 @@ def main():
     single_mean = sum(singles) / len(singles)
     single_sigma = (sum((v - single_mean) ** 2 for v in singles) / (len(singles) - 1)) ** 0.5
 
-    # light self-check so a broken kernel cannot post a number: Parseval on a slice
+    # self-check so a broken kernel cannot post a number: Parseval on every rank's first 64 transforms; on rank 0 sampled
+    # transforms of the timed output against the CPU oracle's fp64 DFT/N of the regenerated input
     xs = x[: 64 * 2 * N].float().reshape(64, 2 * N)
     ys = y[: 64 * 2 * N].float().reshape(64, 2 * N)
     par = float((((ys ** 2).sum(1) - (xs ** 2).sum(1) / N).abs() / ((xs ** 2).sum(1) / N)).max())
@@ -231,12 +379,19 @@ def main():
         raise SystemExit(f"self-check failed: Parseval mismatch {par:.3e}")
 
     if rank == 0:
+        from oracle import orc
+
+        ids = sorted({0, 1, batch // 2 + 3, batch - 1})
+        oracle_err = check_transforms(torch, orc, y, N, batch, ids, first_fft=first_fft)
         samples_per_step = float(N) * batch * world
         value = samples_per_step * args.steps / wall / 1e9
         alg_bytes = plan.algorithmic_bytes                      # per launch, this rank
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         mfma_tflops = plan.mfma_flops / (kernel_ms * 1e-3) / 1e12
         traffic = measured_traffic(plan.kernel_name) if batch == BATCH else None
+        workload = ("BASELINE configs[1]: batched 1D N=4096 fp16 C2C FFT, batch=65536 on one GPU" if (world == 1 and batch == BATCH)
+                    else f"BASELINE configs[4a] share: batched 1D N=4096 fp16 C2C FFT, batch={batch} per GPU "
+                         f"({batch * world} transforms over {world} GPU(s); configs[4a] = 2^24 over 8)")
         line = {
             "metric": "Gsamples/s + %fp16-MFMA-peak, batched N=4096 fp16 C2C FFT",
             "value": value,
@@ -251,12 +406,16 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: batched 1D N=4096 fp16 C2C FFT, batch=65536 per GPU, "
-                            "planar [RE|IM] blocks resident in HBM, result = DFT(x)/N",
+                "workload": workload + ", planar [RE|IM] blocks resident in HBM, result = DFT(x)/N",
                 "n": N,
                 "batch_per_gpu": batch,
+                "input": f"uniform(-1,1) binary16 from the counter-hash generator (tfft_synth_uniform, seed {SEED}, global "
+                         "transform index), reproducible on the CPU",
                 "clock_ramp_launches": RAMP,
+                "cold_ms_per_step": cold_ms,
                 "parallelism": f"batch sharded over {world} GPU(s), no data-path collective",
+                "self_check": f"transforms {ids} of rank 0's timed output vs the CPU oracle's fp64 DFT/N: rel-L2 {oracle_err:.2e}; "
+                              f"Parseval on 64 transforms per rank: {par:.1e}",
             },
             "roofline": {
                 "bound": "hbm",
@@ -277,7 +436,7 @@ def main():
         if world == 1 and not args.no_other_configs and batch == BATCH:
             del x, y
             torch.cuda.empty_cache()
-            line["other_configs"] = other_configs(torch, tf, local_rank)
+            line["other_configs"] = other_configs(torch, tf, orc, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -224,6 +224,14 @@ int tfft_permute_twiddle(const void* in_re, const void* in_im, void* out_re, voi
 int tfft_deinterleave(const void* in_half2, void* out_re, void* out_im, uint64_t count, void* stream);
 int tfft_interleave(const void* in_re, const void* in_im, void* out_half2, uint64_t count, void* stream);
 
+/* Synthetic input born on the device: planes re / im (transform b at + b * batch_stride halves, 0 = 2 n) are filled with
+ * uniform(-1, 1) binary16 samples, each a pure function of (seed, first_fft + b, plane, sample index): a counter-based
+ * hash, so any sub-batch can be regenerated elsewhere (the CPU-side checker restates the same function) and a benchmark can check
+ * sampled transforms of a batch that never existed on the host. The reference creates its signals on the GPU
+ * too (src/testing/TestingDataCreation.h:29-147, 152-193), one transform at a time through the host. n % 8 == 0. */
+int tfft_synth_uniform(void* re, void* im, uint64_t n, uint64_t batch, uint64_t batch_stride, uint64_t first_fft,
+                       uint64_t seed, void* stream);
+
 /* Name of the dominant kernel of this plan (for profiler summaries) and the
  * algorithmic HBM bytes / MFMA flops of one tfft_exec (SURVEY 8d accounting). */
 const char* tfft_plan_kernel_name(const tfft_plan* plan);

@@ -54,6 +54,8 @@ def lib():
         L.orc_dft64.argtypes = [u64, u64, u16p, u16p, u64, f64p, f64p, u64, ctypes.c_int, ctypes.c_int]
         L.orc_fft64_rows.restype = ctypes.c_int
         L.orc_fft64_rows.argtypes = [u64, u64, f64p, f64p, u64]
+        L.orc_synth_uniform.restype = None
+        L.orc_synth_uniform.argtypes = [u64, u64, u64, u64, u16p]
         L.orc_random_weights.restype = None
         L.orc_random_weights.argtypes = [ctypes.c_int, ctypes.c_int, f32p]
         L.orc_sine_superposition.restype = None
@@ -116,12 +118,17 @@ def ref_fft(re, im, mode=MODE_4096):
     return orr.view(np.float16), oi.view(np.float16)
 
 
-def dft64(re, im, algo=1, threads=0):
-    """fp64 DFT(x)/N of fp16 planar input. algo 0 naive, 1 radix-2 FFT."""
+def dft64(re, im, algo=1, threads=0, out=None):
+    """fp64 DFT(x)/N of fp16 planar input. algo 0 naive, 1 radix-2 FFT. out: optional preallocated (re, im) float64
+    pair of shape (batch, n) (timing loops reuse it, so that page-faulting fresh output arrays is not what they time)."""
     rb, ib = _as_bits(re), _as_bits(im)
     batch, n = rb.shape
-    orr = np.empty((batch, n), dtype=np.float64)
-    oi = np.empty((batch, n), dtype=np.float64)
+    if out is not None:
+        orr, oi = out
+        assert orr.shape == (batch, n) and oi.shape == (batch, n) and orr.dtype == np.float64 and oi.dtype == np.float64
+    else:
+        orr = np.empty((batch, n), dtype=np.float64)
+        oi = np.empty((batch, n), dtype=np.float64)
     rc = lib().orc_dft64(n, batch, _u16(rb), _u16(ib), n, _f64(orr), _f64(oi), n, algo, threads)
     if rc:
         raise ValueError(f"orc_dft64 rc={rc}")
@@ -138,6 +145,14 @@ def fft64_rows(z):
     if rc:
         raise ValueError(f"orc_fft64_rows rc={rc}")
     return (re + 1j * im).reshape(z.shape)
+
+
+def synth_uniform(n, batch, first_fft=0, seed=42):
+    """CPU twin of tfft_synth_uniform: float16 (re, im), each (batch, n), of transforms first_fft .. first_fft + batch - 1."""
+    out = np.empty((batch, 2, n), dtype=np.uint16)
+    lib().orc_synth_uniform(n, batch, first_fft, seed, _u16(out))
+    h = out.view(np.float16)
+    return np.ascontiguousarray(h[:, 0]), np.ascontiguousarray(h[:, 1])
 
 
 def random_weights(count, seed):

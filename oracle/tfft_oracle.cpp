@@ -541,6 +541,31 @@ int orc_fft64_rows(uint64_t n, uint64_t batch, double* re, double* im, uint64_t 
   return 0;
 }
 
+// CPU twin of the library's device-side input generator (tensor-fft_amd/csrc/synth.hpp, tfft_synth_uniform; restated
+// here, nothing is shared with the product): sample (fft, plane, j) = binary16 of ((h >> 41) - 2^22 + 1/2) 2^-22 with
+// h = mix(mix(seed + 0x9E3779B97F4A7C15 (fft + 1)) ^ (2 j + plane)), mix = the splitmix64 finaliser. out = [RE n | IM n]
+// per transform.
+static inline uint64_t synth_mix64(uint64_t z) {
+  z ^= z >> 30;
+  z *= 0xbf58476d1ce4e5b9ull;
+  z ^= z >> 27;
+  z *= 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return z;
+}
+void orc_synth_uniform(uint64_t n, uint64_t batch, uint64_t first_fft, uint64_t seed, uint16_t* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < static_cast<int64_t>(batch); ++b) {
+    const uint64_t s1 = synth_mix64(seed + 0x9E3779B97F4A7C15ull * (first_fft + b + 1));
+    for (uint32_t plane = 0; plane < 2; ++plane)
+      for (uint64_t j = 0; j < n; ++j) {
+        const uint64_t h = synth_mix64(s1 ^ (2 * j + plane));
+        const double x = (static_cast<double>(static_cast<int64_t>(h >> 41) - (1 << 22)) + 0.5) / 4194304.0;
+        out[(2 * b + plane) * n + j] = d2h(x);
+      }
+  }
+}
+
 // GetRandomWeights (TestingDataCreation.h:15-27): same std:: machinery.
 void orc_random_weights(int count, int seed, float* out) {
   std::seed_seq seq = {seed};

@@ -17,7 +17,7 @@ Two layers, both thin:
   memory and streams only.
 """
 from .capi import (TfftError, TfftPlan, TfftPlan2D, device_check, lib_path, load_library, plan_describe,  # noqa: F401
-                   ref_create_plan)
+                   ref_create_plan, synth_uniform, transposed_n2, variant_check)
 from .reference_api import (  # noqa: F401
     ComputeFFT,
     CreatePlan,
@@ -32,6 +32,7 @@ from .reference_api import (  # noqa: F401
 
 __all__ = [
     "TfftError", "TfftPlan", "TfftPlan2D", "device_check", "lib_path", "load_library", "plan_describe", "ref_create_plan",
+    "synth_uniform", "transposed_n2", "variant_check",
     "ComputeFFT", "CreatePlan", "DataBatchHandler", "DataHandler", "GetMaxNoOptInSharedMem",
     "Mode_256", "Mode_4096", "Plan", "PlanWorksOnDevice",
 ]

@@ -19,7 +19,7 @@ SYMBOLS = [
     "tfft_last_error", "tfft_version", "tfft_permute_twiddle", "tfft_exec_inverse", "tfft_deinterleave", "tfft_interleave",
     "tfft_plan2d_create", "tfft_plan2d_destroy", "tfft_plan2d_num_launches", "tfft_plan2d_workspace_bytes",
     "tfft_plan2d_set_workspace", "tfft_plan2d_exec", "tfft_plan2d_exec_inverse", "tfft_plan_describe",
-    "tfft_variant_check", "tfft_plan_transposed_n2",
+    "tfft_variant_check", "tfft_plan_transposed_n2", "tfft_synth_uniform",
 ]
 
 SCALE_SEQUENTIAL, SCALE_NONE, SCALE_ONCE = 0, 1, 2           # tfft_plan_opts.scale
@@ -139,6 +139,8 @@ def load_library():
     L.tfft_variant_check.argtypes = [u64, u64, ci]
     L.tfft_plan_transposed_n2.restype = u64
     L.tfft_plan_transposed_n2.argtypes = [u64]
+    L.tfft_synth_uniform.restype = ci
+    L.tfft_synth_uniform.argtypes = [vp, vp, u64, u64, u64, u64, u64, vp]
     L.tfft_plan_kernel_name.restype = ctypes.c_char_p
     L.tfft_plan_kernel_name.argtypes = [vp]
     L.tfft_plan_algorithmic_bytes.restype = ctypes.c_double
@@ -340,6 +342,24 @@ class TfftPlan2D:
             self.close()
         except Exception:   # noqa: BLE001 - interpreter shutdown
             pass
+
+
+def synth_uniform(re, im, n, batch, batch_stride=0, first_fft=0, seed=42, stream=None):
+    """Fills planar CUDA half planes with the counter-hash uniform(-1, 1) signal (tfft_synth_uniform): element
+    (first_fft + b, plane, j) is a pure function of the seed, so a CPU-side checker can regenerate any transform of it."""
+    import torch
+
+    stride = int(batch_stride) or 2 * int(n)
+    need = (int(batch) - 1) * stride + int(n)
+    for t in (re, im):
+        if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.numel() >= need):
+            raise TfftError(5, "planes must be contiguous CUDA float16 tensors of (batch-1)*stride + n elements")
+    dev = re.device.index
+    if stream is None:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        _check(load_library().tfft_synth_uniform(re.data_ptr(), im.data_ptr(), int(n), int(batch), stride, int(first_fft),
+                                                 int(seed), stream))
 
 
 def deinterleave(x_half2, out_re, out_im, stream=None):

@@ -25,6 +25,7 @@
 #include "colfft.hpp"
 #include "permute.hpp"
 #include "stockham.hpp"
+#include "synth.hpp"
 
 namespace {
 
@@ -1080,6 +1081,15 @@ int tfft_exec(const tfft_plan* p, const void* in_re, const void* in_im, void* ou
   // in_im, shifted or partially overlapping blocks) would be read after it has been overwritten by another workgroup
   // or by an earlier pass of the chain.
   const bool same_re = in_re == out_re, same_im = in_im == out_im;
+  // (a pass with re-mapped output rows, the second pass of the fused 2D plan, is only reachable through
+  // tfft_plan2d_exec, which owns both of its buffers)
+  const bool remapped = p->out_row_shift || p->out_sub_shift;
+  if (remapped) {
+    int cur0 = 0;
+    TFFT_HIP(hipGetDevice(&cur0));
+    if (cur0 != p->device) return fail(TFFT_ERR_ARG, "plan was created for another device than the current one");
+    return launch_chain(p, in_re, in_im, out_re, out_im, static_cast<hipStream_t>(stream));
+  }
   if ((same_re || same_im) && p->in_stride != p->out_stride)
     return fail(TFFT_ERR_ARG, "in-place execution needs equal input and output batch strides");
   if ((!same_re && planes_overlap(in_re, p->in_stride, out_re, p->out_stride, p->batch, nf)) ||
@@ -1319,6 +1329,22 @@ int tfft_interleave(const void* in_re, const void* in_im, void* out_half2, uint6
   hipLaunchKernelGGL(permute::interleave_kernel, dim3(grid), dim3(permute::kBlock), 0, static_cast<hipStream_t>(stream),
                      static_cast<const permute::uv4*>(in_re), static_cast<const permute::uv4*>(in_im),
                      static_cast<permute::uv4*>(out_half2), n8);
+  TFFT_HIP(hipGetLastError());
+  return TFFT_OK;
+}
+
+int tfft_synth_uniform(void* re, void* im, uint64_t n, uint64_t batch, uint64_t batch_stride, uint64_t first_fft,
+                       uint64_t seed, void* stream) {
+  g_err.clear();
+  if (!re || !im) return fail(TFFT_ERR_ARG, "null data pointer");
+  if (n == 0 || (n % 8) || batch == 0) return fail(TFFT_ERR_ARG, "n must be a positive multiple of 8 and batch positive");
+  if (batch_stride == 0) batch_stride = 2 * n;
+  if (batch_stride < n || (batch_stride % 8)) return fail(TFFT_ERR_ARG, "batch stride must be a multiple of 8 halves and >= n");
+  if ((reinterpret_cast<uintptr_t>(re) | reinterpret_cast<uintptr_t>(im)) & 15) return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
+  const uint64_t total = batch * 2 * (n / 8);
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((total + synth::kBlock - 1) / synth::kBlock, 1u << 20));
+  hipLaunchKernelGGL(synth::uniform_kernel, dim3(grid), dim3(synth::kBlock), 0, static_cast<hipStream_t>(stream),
+                     static_cast<uint16_t*>(re), static_cast<uint16_t*>(im), n / 8, batch, batch_stride, first_fft, seed);
   TFFT_HIP(hipGetLastError());
   return TFFT_OK;
 }

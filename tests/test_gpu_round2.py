@@ -7,11 +7,16 @@
 * WRONG-result debugging variants are refused; aliasing rules of tfft_exec;
 * scale modes (TFFT_SCALE_NONE / ONCE), transposed output order, the four-step twiddle of the column pass.
 
-Stated ULP tolerance (north_star: "matches the reference CUDA kernel within a stated fp16 ULP tolerance"): for every
-output element, |HIP - restatement| <= ULP_TOL fp16 ulps, the ulp taken at max(|restatement element|, rms of the
-spectrum's components). Both paths approximate the same DFT(x)/N; the restatement rounds its accumulators to fp16 after
-every MMA (Ampere HMMA model), the HIP path accumulates in fp32, so the distance is dominated by the restatement's own
-error (about 4 ulp at the spectrum's rms for white input)."""
+Stated ULP tolerance (north_star: "matches the reference CUDA kernel within a stated fp16 ULP tolerance"):
+    max over all output elements of |HIP - restatement|  <=  ULP_TOL = 2.5 fp16 ulp of the LARGEST spectrum component
+(real or imaginary part), for any input; for white input, whose spectrum is flat, also <= ULP_TOL_RMS = 10 ulp taken at
+max(|element|, rms of the components). Both paths approximate the same DFT(x)/N; the restatement rounds its
+accumulators to fp16 after every MMA (Ampere HMMA model), the HIP path accumulates in fp32, so the distance is dominated
+by the restatement's own error. Measured on MI355X, N = 2^8 .. 2^20, both base modes, uniform data and the reference's
+benchmark signal (tools/ulp_probe.py, profiles/r2_ulp_distances.txt): HIP vs restatement 1.00 .. 2.12 ulp(max), HIP vs
+fp64 DFT/N 0.50 .. 1.15, restatement vs fp64 DFT/N 0.79 .. 2.11. (A sparse spectrum such as the benchmark signal's has
+an rms far below its lines, so an ulp-at-rms figure is meaningless there: the restatement itself leaks 30 .. 250
+ulp-at-rms into empty bins at N >= 2^13.)"""
 import glob
 import os
 import subprocess
@@ -23,7 +28,8 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REL_L2_TOL = 1.5e-3
-ULP_TOL = 8.0
+ULP_TOL = 2.5        # ulp of the largest spectrum component
+ULP_TOL_RMS = 10.0   # white input: ulp at max(|element|, rms)
 
 
 @pytest.fixture(scope="module")
@@ -63,10 +69,13 @@ def _run(tf, torch, re, im, **plan_kw):
     return o[:, 0], o[:, 1]
 
 
-def ulp_distance(got_re, got_im, ref_re, ref_im):
-    """max over elements of |got - ref| in fp16 ulps at max(|ref element|, rms of the reference spectrum's components)."""
+def ulp_distance(got_re, got_im, ref_re, ref_im, at="max"):
+    """max over elements of |got - ref| in fp16 ulps. at="max": the ulp of the largest component of the reference
+    spectrum; at="rms": per element, the ulp at max(|ref element|, rms of the reference spectrum's components)."""
     g = np.concatenate([np.asarray(got_re, np.float64).ravel(), np.asarray(got_im, np.float64).ravel()])
     r = np.concatenate([np.asarray(ref_re, np.float64).ravel(), np.asarray(ref_im, np.float64).ravel()])
+    if at == "max":
+        return float(np.abs(g - r).max() / 2.0 ** (np.floor(np.log2(np.abs(r).max())) - 10))
     rms = np.sqrt(np.mean(r * r))
     mag = np.maximum(np.abs(r), max(rms, 2.0 ** -14))
     ulp = 2.0 ** (np.floor(np.log2(mag)) - 10)
@@ -87,8 +96,9 @@ def test_ulp_distance_to_reference_restatement_uniform(tf, torch, orc, lg):
     for mode in ((orc.MODE_256,) if n < 4096 else (orc.MODE_256, orc.MODE_4096)):
         rr, ri = orc.ref_fft(re, im, mode)
         d = max(ulp_distance(gr[b], gi[b], rr[b], ri[b]) for b in range(batch))
-        print(f"N=2^{lg} mode {mode}: max distance HIP vs restatement = {d:.2f} fp16 ulp")
-        assert d <= ULP_TOL, (lg, mode, d)
+        d_rms = max(ulp_distance(gr[b], gi[b], rr[b], ri[b], at="rms") for b in range(batch))
+        print(f"N=2^{lg} mode {mode}: HIP vs restatement {d:.2f} ulp(max), {d_rms:.2f} ulp(rms)")
+        assert d <= ULP_TOL and d_rms <= ULP_TOL_RMS, (lg, mode, d, d_rms)
 
 
 @pytest.mark.parametrize("lg", [8, 12, 13, 16, 20])
@@ -319,7 +329,7 @@ def test_scale_modes(tf, torch, orc, n, inner, variant, scale):
     """NONE: out = DFT(x) = N x the oracle's DFT(x)/N. ONCE: out = DFT(x)/N with a single scaling step. Inputs are sized
     so that N max|x| stays inside fp16 (the documented overflow bound of the unscaled stages)."""
     batch = 2
-    amp = min(1.0, 16384.0 / n)
+    amp = min(1.0, 16384.0 / n) if scale == "none" else 1.0
     rng = np.random.default_rng(n + inner + len(scale))
     re = (rng.uniform(-1, 1, (batch, n, inner)) * amp).astype(np.float16)
     im = (rng.uniform(-1, 1, (batch, n, inner)) * amp).astype(np.float16)
@@ -341,24 +351,27 @@ def test_scale_modes(tf, torch, orc, n, inner, variant, scale):
 @pytest.mark.parametrize("n", [256, 4096, 8192, 1 << 16, 1 << 20])
 def test_scale_modes_are_exact_powers_of_two_apart(tf, torch, n):
     """Away from overflow and underflow the three modes produce the same significands: NONE == N x SEQUENTIAL and
-    ONCE == SEQUENTIAL, bit for bit (every scaling factor is a power of two). Input amplitude 1/4 with N max|x| <= 2^14
-    ... 2^18 would overflow, so the check uses a sparse spectrum: a few tones of small amplitude."""
+    ONCE == SEQUENTIAL, bit for bit (every scaling factor is a power of two). White input of a size that keeps NONE
+    below 65504 would push SEQUENTIAL's spectrum into the subnormals at large N, so the check uses a few tones."""
     batch = 2
     t = np.arange(n)
     x = np.zeros((batch, n), complex)
     for b in range(batch):
         for f, a in ((3, 0.25), (n // 2 - 1, 0.125), (n // 3, 0.0625 * (b + 1))):
             x[b] += a * np.exp(2j * np.pi * ((f * t) % n) / n)
-    x *= 8.0 / n if n > 4096 else 1.0 / 256                           # N max|x| stays below 8 (or 16): no overflow in NONE
+    x *= 16384.0 / n                                                  # NONE: lines of 4096, 2048, 1024 (b + 1): no overflow;
+                                                                      # SEQUENTIAL: the same / N, normal numbers up to N = 2^20
     re, im = x.real.astype(np.float16), x.imag.astype(np.float16)
     seq = _run(tf, torch, re, im)
     non = _run(tf, torch, re, im, scale="none")
     once = _run(tf, torch, re, im, scale="once")
-    s = _c(*seq)
-    big = np.abs(s) > 2.0 ** -13                                       # compare where SEQUENTIAL is not subnormal
+    # component by component on the spectral lines (the bins in between hold the input's quantisation noise, whose
+    # SEQUENTIAL intermediates dip into the subnormals)
+    s = np.concatenate([seq[0].ravel(), seq[1].ravel()]).astype(np.float64)
+    big = (np.abs(s) > 2.0 ** -13) & (np.abs(s) >= np.abs(s).max() / 16)
     assert big.sum() >= 3 * batch
-    assert np.array_equal((_c(*non))[big], (s * n)[big])
-    assert np.array_equal((_c(*once))[big], s[big])
+    assert np.array_equal(np.concatenate([non[0].ravel(), non[1].ravel()]).astype(np.float64)[big], (s * n)[big])
+    assert np.array_equal(np.concatenate([once[0].ravel(), once[1].ravel()]).astype(np.float64)[big], s[big])
 
 
 def test_unscaled_overflow_bound(tf, torch):
