@@ -10,14 +10,15 @@
 //                                                                    headroom for the rotation, returned after stage 2)
 //   X[R kk + s] = DFT_4096(u_s)[kk] / 4096                           (the three MFMA stages of k4096.hpp, unchanged)
 //
-// Wave s of a group copies block s (4096 contiguous points, one LDS-DMA stream, the 4096 kernel's swizzled image) into
-// its own 16-KiB LDS region. After a workgroup barrier the group does the radix-R butterfly IN PLACE across its R
-// regions: every wave owns 1/R of the sample positions, reads the R samples x[m + 4096 r] of each, computes all R
-// outputs (DFT_R in registers, twiddles w_N^(m s) as powers of w_N^m, one rounding to binary16) and writes u_s[m] back to
-// region s at the same position. Region s then holds u_s in exactly the image the 4096 kernel expects, and stages 1-3
-// are that kernel's. The R spectra are staged in the R regions and read out interleaved (X[R kk + s]: 8 / R consecutive
+// Every wave owns 1/R of the sample positions m of its group's transform: it loads the R samples x[m + 4096 r] of each
+// straight from HBM into registers (16-byte coalesced loads, issued one iteration ahead), computes all R outputs (DFT_R
+// in registers, twiddles w_N^(m s) as powers of w_N^m, one rounding to binary16) and writes u_s[m] into LDS region s
+// (16 KiB per wave) in the 4096 kernel's swizzled image. After a workgroup barrier region s holds u_s exactly as the 4096
+// kernel expects it, and stages 1-3 are that kernel's, wave s working on region s. (The first version copied the blocks
+// into LDS by LDS-DMA and did the butterfly in place there: one more barrier, 256 KiB more LDS traffic per iteration and,
+// decisively, nothing in flight from HBM while the workgroup computed.) The R spectra are staged in the R regions and read out interleaved (X[R kk + s]: 8 / R consecutive
 // kk from each of the R images make one 16-byte store), so global traffic is full 1-KiB rows in both directions.
-// Four workgroup barriers per transform. (A first version let every wave read all R blocks per stage-1 tile and form only
+// Three workgroup barriers per iteration. (A first version let every wave read all R blocks per stage-1 tile and form only
 // its own u_s: R x the LDS reads and 2.3-3 x the arithmetic per sample; 2^15 ran at 350 Gsamples/s with it.)
 #pragma once
 
@@ -54,19 +55,21 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
 
   for (int i = tid; i < kLdsTableBytes / 16; i += kThreads)
     reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(tables + kOffG)[i];
-  const h8 f_re = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32);
-  const h8 f_im = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32 + 16);
+  h8 f_re = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32);
+  h8 f_im = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32 + 16);
   // (the plan builds this block with a factor 2, k4096::TableScale::tw: it gives back the headroom factor of the front end
   // after two averaging MFMA stages, exact in fp32)
-  const f4 tw_re = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
-  const f4 tw_im = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f4 tw_re = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
+  f4 tw_im = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
+  // The constants are operands of this statement, so the compiler has to have them in registers HERE (it waits for their
+  // loads now and knows they have landed). Left to itself it sinks these loads (restrict + const: movable across the
+  // "memory" clobber) below the first prefetch and then guards their first use, inside the loop, with s_waitcnt vmcnt(0..3),
+  // which in steady state waits for the NEXT iteration's input that was issued just before: no overlap left.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_re), "+v"(f_im), "+v"(tw_re), "+v"(tw_im) : : "memory");
   __syncthreads();
 
   uint8_t* const wl = lds + kLdsTableBytes + wave * kLdsWaveBytes;                 // this wave's region
   uint8_t* const gl = lds + kLdsTableBytes + (grp * R) * kLdsWaveBytes;            // region of the group's block 0
-  const uint32_t wl_off = __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)wl)));
   const uint8_t* const g_tab = lds + lane * 16;
   const uint8_t* const h_tab = lds + 16384 + lane * 16;
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
@@ -81,24 +84,47 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
 
   static_assert(!ROWS || R == 8, "the 2D row form takes the 8 rows r0 + 512 i of an image");
   const uint32_t groups_total = ROWS ? batch : (batch + kGroups - 1) / kGroups;
+  constexpr int kPs = 8 / R;                 // 16-byte chunks per lane, block and plane that this wave owns
+
+  // Raw samples of one iteration: this wave's chunk positions of all R blocks, both planes, straight from HBM into
+  // registers (16 x global_load_dwordx4, 1 KiB per wave instruction, non-temporal). The loads of iteration i + 1 are
+  // issued as soon as the front end of iteration i has consumed these registers, so they fly under the three MFMA
+  // stages, the read-out and the stores of iteration i: the kernel never sits waiting for its input with nothing
+  // else to do, which is what the LDS-DMA version did between its barriers D and A (one 160-KiB workgroup per CU,
+  // 3.6-3.9 TB/s; PMC: 35 % of the wave time parked in s_waitcnt / s_barrier).
+  u4 raw_r[kPs][R], raw_i[kPs][R];
+  auto issue_loads = [&](uint32_t it) {
+    const uint32_t b_raw = ROWS ? (it >> 9) : it * kGroups + grp;
+    const uint32_t b = (ROWS || b_raw < batch) ? b_raw : batch - 1;     // past the end: re-read the last transform
+    const uint32_t r0 = it & 511;
+    const uint16_t* const base_re = in_re + in_map.off(b) + (ROWS ? static_cast<uint64_t>(r0) * 4096 : 0);
+    const uint16_t* const base_im = in_im + in_map.off(b) + (ROWS ? static_cast<uint64_t>(r0) * 4096 : 0);
+    constexpr uint64_t kBlockStep = ROWS ? 512ull * 4096 : 4096ull;     // block r of the group: rows r0 + 512 r, or samples 4096 r
+#pragma unroll
+    for (int ps = 0; ps < kPs; ++ps) {
+      const uint32_t chunk = 64u * (s * kPs + ps) + lane;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        raw_r[ps][r] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(base_re + kBlockStep * r + 8 * chunk));
+        raw_i[ps][r] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(base_im + kBlockStep * r + 8 * chunk));
+      }
+    }
+  };
+  if (blockIdx.x < groups_total) issue_loads(blockIdx.x);
+
   for (uint32_t it = blockIdx.x; it < groups_total; it += gridDim.x) {
     // a group past the end of the batch re-does the last transform (it keeps the barriers uniform) without storing
     const uint32_t b_raw = ROWS ? (it >> 9) : it * kGroups + grp;      // ROWS: image index; r0 = it & 511
     const bool live = ROWS || b_raw < batch;
     const uint32_t b = live ? b_raw : batch - 1;
     const uint32_t r0 = it & 511;
-    const uint64_t in_off = ROWS ? static_cast<uint64_t>(r0 + 512 * s) * 4096 : 4096ull * s;
-    dma_in<true>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(b) + in_off),
-                 reinterpret_cast<const uint8_t*>(in_im + in_map.off(b) + in_off), wl_off, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // A: all R blocks of every group's transform are in LDS
 
-    // ---- radix-R front end, IN PLACE across the group's R regions: this wave owns 8 / R chunks per lane (16 bytes =
-    // 8 consecutive m) of every block, so each sample is read once and each u_s[m] written once; no other wave
-    // touches these positions, hence no barrier inside. Region s ends up holding u_s in the 4096 kernel's image.
+    // ---- radix-R front end, registers -> the group's R LDS regions: this wave owns 8 / R chunks per lane (16 bytes =
+    // 8 consecutive m) of every block, so each sample is read once and each u_s[m] written once. Region s ends up
+    // holding u_s in the 4096 kernel's (swizzled) image.
 #pragma unroll
-    for (int ps = 0; ps < 8 / R; ++ps) {
-      const int mm = s * (8 / R) + ps;                               // 1-KiB block of the plane: chunks 64 mm .. 64 mm + 63
+    for (int ps = 0; ps < kPs; ++ps) {
+      const int mm = s * kPs + ps;                                   // 1-KiB block of the plane: chunks 64 mm .. 64 mm + 63
       const uint32_t slot = mm * 1024 + 16 * (lane ^ (2 * mm));      // LDS slot of global chunk c = 64 mm + lane
       // w_N^m, m = m0 + e (1D) or the per-iteration scalar w_4096^r0 (2D rows)
       const float rev0 = ROWS ? static_cast<float>(r0) * (1.0f / 4096) : static_cast<float>(8 * (64 * mm + lane)) * (1.0f / kN);
@@ -107,8 +133,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       uint32_t in_r[R][4], in_i[R][4];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const u4 vr = *reinterpret_cast<const u4*>(gl + r * kLdsWaveBytes + slot);
-        const u4 vi = *reinterpret_cast<const u4*>(gl + r * kLdsWaveBytes + 8192 + slot);
+        const u4 vr = raw_r[ps][r];
+        const u4 vi = raw_i[ps][r];
         in_r[r][0] = vr.x; in_r[r][1] = vr.y; in_r[r][2] = vr.z; in_r[r][3] = vr.w;
         in_i[r][0] = vi.x; in_i[r][1] = vi.y; in_i[r][2] = vi.z; in_i[r][3] = vi.w;
       }
@@ -125,13 +151,13 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
             v[r] = stockham::cf{static_cast<float>(hr[lo]), static_cast<float>(hi[lo])};
           }
           stockham::dft<R>(v);
-          // u_s = v[s] w_N^(s m) / (2 R): powers of w1 = w_N^m
-          float pw_re = w1_re, pw_im = w1_im;
+          // u_s = v[s] w_N^(s m) / (2 R): powers of w1 = w_N^m, the factor 1 / (2 R) riding on them
+          float pw_re = w1_re * (0.5f / R), pw_im = w1_im * (0.5f / R);
           ur[lo][0] = v[0].re * (0.5f / R);
           ui[lo][0] = v[0].im * (0.5f / R);
 #pragma unroll
           for (int s2 = 1; s2 < R; ++s2) {
-            const float xr = v[s2].re * (0.5f / R), xi = v[s2].im * (0.5f / R);
+            const float xr = v[s2].re, xi = v[s2].im;
             ur[lo][s2] = __builtin_fmaf(xr, pw_re, -(xi * pw_im));
             ui[lo][s2] = __builtin_fmaf(xr, pw_im, xi * pw_re);
             if (s2 + 1 < R) {
@@ -165,6 +191,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // B: u_0 .. u_(R-1) are complete
+    // the raw registers are free: the next iteration's input starts flying now
+    if (it + gridDim.x < groups_total) issue_loads(it + gridDim.x);
 
     // ---- stage 1 on this wave's own region, exactly the 4096 kernel's: D1_n1[k0 = 4g + r][n0 = lane & 15]
     uint32_t pr[8][4], pi[8][4];
@@ -256,7 +284,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(row_re + 512 * i + 8 * lane));
         __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(row_im + 512 * i + 8 * lane));
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read out before this wave's next copy-in lands on the region
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // D: every region has been read out before the next front end writes into it
       continue;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

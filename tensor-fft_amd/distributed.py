@@ -1,28 +1,34 @@
-"""One 1D transform spread over the GPUs of a node: four-step FFT with ONE all-to-all.
+"""One 1D transform spread over the GPUs of a node: four-step FFT with ONE exchange.
 
 The reference has nothing to compare with (its multi-GPU code is commented out and ran independent FFTs
 per device, src/base/ComputeFFT.h:295-411). MI355X-native plan: one process per GPU,
-``torch.distributed`` over RCCL/xGMI, the exchange is a single ``all_to_all_single`` per plane in which
-every rank sends one chunk to each of its 7 peers (all xGMI links busy at once); everything either side of
-it is local: radix passes along a strided axis, and one fused re-order + twiddle kernel.
+``torch.distributed`` over RCCL/xGMI. The exchange is one grouped send/recv (``batch_isend_irecv`` = one
+ncclGroupStart/End) in which every rank sends one chunk of BOTH planes to each of its peers (all xGMI links busy at
+once); everything either side of it is local.
 
 N = N1 * N2, x viewed as [N1][N2] (n = n1 N2 + n2), X[k1 + N1 k2]:
 
     layout "columns" (input):   rank p owns x[n1 N2 + p C + c], c < C = N2 / P, stored [N1][C]
     1. FFT over n1 (length N1, strided axis, C columns innermost)            -> Y[k1][c]      local
-    2. all-to-all: rows k1 in [q K, (q+1) K), K = N1 / P, go to rank q       (contiguous chunks, no packing)
-    3. re-order [p'][k][c] -> [k][p' C + c] fused with the twiddle w_N^(k1 n2)                  local
-    4. FFT over n2 (length N2, contiguous rows, batch K)                     -> X[k1 + N1 k2]   local
+    2. twiddle w_N^(k1 n2), n2 = p C + c                                                     local
+    3. exchange: rows k1 in [q K, (q+1) K), K = N1 / P, go to rank q         (contiguous chunks, no packing)
+    4. re-order [p'][k][c] -> [k][p' C + c]                                                   local
+    5. FFT over n2 (length N2, contiguous rows, batch K)                     -> X[k1 + N1 k2]   local
     layout "transposed" (output): rank q owns k1 in its block, all k2, stored [K][N2]
 
+Fused form (N1 = 256 or 512 and C a multiple of 64; this is what N = 2^26 on 8 GPUs takes): steps 1 and 2 are ONE
+radix-N1 column pass whose epilogue applies the four-step twiddle (tfft_plan_opts.fourstep_n, column offset p C), so
+step 4 is a pure re-order and at world size 1 disappears together with the exchange: the local work is then exactly
+the library's transposed-order plan. General form (any other geometry): balanced split N1 ~ N2, steps 2 and 4 in
+one fused re-order + twiddle kernel after the exchange.
+
 ``input_layout="natural"`` / ``output_layout="natural"`` (contiguous blocks of x / X per rank) cost one more
-all-to-all each, plus a pack / unpack re-order.
+exchange each, plus a pack / unpack re-order.
 
 The class holds only index logic and the collective; arithmetic is delegated to an *engine*
 (:class:`HipEngine` = libtfft.so on the GPU). Tests drive the same logic on CPU tensors over gloo with an
 engine of their own.
 """
-import math
 
 
 def _ilog2(x):
@@ -30,7 +36,8 @@ def _ilog2(x):
 
 
 class HipEngine:
-    """Local arithmetic on the GPU through the C ABI (no other implementation exists in this package)."""
+    """Local arithmetic on the GPU through the C ABI (no other implementation exists in this package). Every
+    intermediate lives in a buffer the engine allocates once per (role, size) and reuses on every forward()."""
 
     def __init__(self, device):
         from . import capi
@@ -38,42 +45,63 @@ class HipEngine:
         self.capi = capi
         self.device = device
         self._plans = {}
+        self._bufs = {}
 
-    def _plan(self, n, batch, inner):
-        key = (n, batch, inner)
+    def _plan(self, n, batch, inner, **kw):
+        key = (n, batch, inner, tuple(sorted(kw.items())))
         p = self._plans.get(key)
         if p is None:
+            import torch
+
             p = self.capi.TfftPlan(n, batch, self.device, inner=inner, in_batch_stride=n * inner,
-                                   out_batch_stride=n * inner, preserve_input=True)
+                                   out_batch_stride=n * inner, preserve_input=True, **kw)
+            if p.workspace_bytes:            # scratch owned by torch, handed over once
+                p.set_workspace(torch.empty(p.workspace_bytes // 2, dtype=torch.float16, device=f"cuda:{self.device}"))
             self._plans[key] = p
         return p
 
-    def empty_like(self, t):
+    def buffers(self, role, like):
+        """The (re, im) pair of this role, same shape / dtype / device as `like`; allocated on first use."""
         import torch
 
-        return torch.empty_like(t)
+        key = (role, like.numel(), like.dtype, like.device)
+        b = self._bufs.get(key)
+        if b is None:
+            b = (torch.empty_like(like), torch.empty_like(like))
+            self._bufs[key] = b
+        return b
 
     def fft_strided(self, re, im, n, inner):
         """FFT/n along axis 0 of [n][inner] planes."""
-        o_re, o_im = self.empty_like(re), self.empty_like(im)
+        o_re, o_im = self.buffers("strided", re)
         self._plan(n, 1, inner).exec(re, im, o_re, o_im)
+        return o_re, o_im
+
+    def supports_fourstep(self, n1, inner):
+        return n1 in (256, 512) and inner >= 64 and inner % 64 == 0
+
+    def fft_strided_fourstep(self, re, im, n1, inner, n_total, col0):
+        """FFT/n1 along axis 0 of [n1][inner] planes, output row k of column c times w_{n_total}^(k (col0 + c)): one
+        column pass (tfft_plan_opts.fourstep_n)."""
+        o_re, o_im = self.buffers("strided", re)
+        self._plan(n1, 1, inner, fourstep_n=n_total, fourstep_col0=col0).exec(re, im, o_re, o_im)
         return o_re, o_im
 
     def fft_rows(self, re, im, n, batch):
         """FFT/n of `batch` contiguous rows of length n."""
-        o_re, o_im = self.empty_like(re), self.empty_like(im)
+        o_re, o_im = self.buffers("rows", re)
         self._plan(n, batch, 1).exec(re, im, o_re, o_im)
         return o_re, o_im
 
-    def permute_twiddle(self, re, im, a, b, c, n_tw=0, e0=0):
+    def permute_twiddle(self, re, im, a, b, c, n_tw=0, e0=0, role="permute"):
         """[a][b][c] -> [b][a][c], times w_n_tw^((e0 + b)(a c_total + c)) when n_tw > 0."""
-        o_re, o_im = self.empty_like(re), self.empty_like(im)
+        o_re, o_im = self.buffers(role, re)
         self.capi.permute_twiddle(re, im, o_re, o_im, a, b, c, n_tw, e0)
         return o_re, o_im
 
 
 class DistributedFFT1D:
-    def __init__(self, n, group=None, engine=None, input_layout="columns", output_layout="transposed"):
+    def __init__(self, n, group=None, engine=None, input_layout="columns", output_layout="transposed", fused=None):
         import torch.distributed as dist
 
         if n & (n - 1) or n < 2:
@@ -87,16 +115,32 @@ class DistributedFFT1D:
             raise ValueError("the number of ranks has to be a power of 2")
         lg = _ilog2(n)
         self.n = n
-        self.n1 = 1 << ((lg + 1) // 2)
-        self.n2 = n // self.n1
+        self.engine = engine
+        # fused form: N1 = 256 or 512 with at least 64 columns per rank (and the engine can do it)
+        self.fused = False
+        can = getattr(engine, "supports_fourstep", None)
+        if fused is not False and can is not None:
+            # prefer the split whose N2 the library transforms in the fewest passes: a single-kernel length (<= 2^15),
+            # 4096 first of all; otherwise N1 = 256 (256-byte row segments in the column pass)
+            order = (512, 256) if (lg - 9 == 12 or (lg - 8 > 15 >= lg - 9)) else (256, 512)
+            for n1 in order:
+                n2 = n // n1
+                if n1 < n and n1 % p == 0 and n2 % p == 0 and can(n1, n2 // p):
+                    self.fused, self.n1, self.n2 = True, n1, n2
+                    break
+        if fused and not self.fused:
+            raise ValueError("the fused four-step form needs N1 = 256 or 512 and at least 64 columns per rank")
+        if not self.fused:
+            self.n1 = 1 << ((lg + 1) // 2)
+            self.n2 = n // self.n1
         if self.n2 % p or self.n1 % p or (self.n2 // p) % 8:
             raise ValueError(f"N = {n} is too small for {p} ranks (needs N2/P >= 8 columns per rank)")
         self.c = self.n2 // p          # columns per rank (step 1)
-        self.k = self.n1 // p          # rows per rank (step 4)
+        self.k = self.n1 // p          # rows per rank (step 5)
         if input_layout not in ("columns", "natural") or output_layout not in ("transposed", "natural"):
             raise ValueError("unknown layout")
         self.input_layout, self.output_layout = input_layout, output_layout
-        self.engine = engine
+        self._recv = {}
 
     # ---- layouts (what each rank holds, as index arrays into x / X; used by callers and tests)
     def input_indices(self, rank=None):
@@ -119,15 +163,40 @@ class DistributedFFT1D:
         k2 = np.arange(self.n2)[None, :]
         return (k1 + self.n1 * k2).reshape(-1)
 
-    def _all_to_all(self, t):
-        if self.world == 1:
-            return t
-        out = t.new_empty(t.shape)
-        self.dist.all_to_all_single(out, t, group=self.group)
-        return out
+    def _exchange(self, re, im, role):
+        """All-to-all of both planes as ONE grouped operation: chunk q of each plane goes to rank q (one
+        ncclGroupStart/End over RCCL: 2 (P - 1) sends and as many receives, every xGMI link busy at once). The receive
+        buffers are allocated once per role."""
+        p = self.world
+        if p == 1:
+            return re, im
+        key = (role, re.numel(), re.dtype, re.device)
+        out = self._recv.get(key)
+        if out is None:
+            out = (re.new_empty(re.shape), im.new_empty(im.shape))
+            self._recv[key] = out
+        o_re, o_im = out
+        chunk = re.numel() // p
+        dist = self.dist
+        ops = []
+        for q in range(p):
+            sl = slice(q * chunk, (q + 1) * chunk)
+            if q == self.rank:
+                o_re[sl].copy_(re[sl])
+                o_im[sl].copy_(im[sl])
+                continue
+            peer = q if self.group is None else dist.get_global_rank(self.group, q)
+            ops.append(dist.P2POp(dist.isend, re[sl], peer, self.group))
+            ops.append(dist.P2POp(dist.isend, im[sl], peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, o_re[sl], peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, o_im[sl], peer, self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return o_re, o_im
 
     def forward(self, re, im):
-        """re, im: this rank's N/P samples (flat float16 tensors in the input layout) -> its N/P outputs."""
+        """re, im: this rank's N/P samples (flat float16 tensors in the input layout) -> its N/P outputs. The returned
+        tensors are buffers owned by the engine / this object: copy them before the next forward() if they must live."""
         e, p = self.engine, self.world
         loc = self.n // p
         if re.numel() != loc or im.numel() != loc:
@@ -135,30 +204,40 @@ class DistributedFFT1D:
         if self.input_layout == "natural" and p > 1:
             # rank holds rows n1 in its block, all n2: [R][P][C] -> chunks [P][R][C], exchange -> [N1][C]
             rows = self.n1 // p
-            re, im = e.permute_twiddle(re, im, rows, p, self.c)
-            re, im = self._all_to_all(re), self._all_to_all(im)
-        # 1. column transforms
-        re, im = e.fft_strided(re, im, self.n1, self.c)
-        # 2. the one exchange of the plain path
-        re, im = self._all_to_all(re), self._all_to_all(im)
-        # 3. [p'][k][c] -> [k][p' C + c], twiddle w_N^((rank K + k)(p' C + c))
-        re, im = e.permute_twiddle(re, im, p, self.k, self.c, self.n, self.rank * self.k)
-        # 4. row transforms
+            re, im = e.permute_twiddle(re, im, rows, p, self.c, role="pack_in")
+            re, im = self._exchange(re, im, "in")
+        if self.fused:
+            # 1 + 2. column transforms with the four-step twiddle in their epilogue
+            re, im = e.fft_strided_fourstep(re, im, self.n1, self.c, self.n, self.rank * self.c)
+            # 3. the one exchange of the plain path, 4. pure re-order (nothing to do on one rank)
+            re, im = self._exchange(re, im, "main")
+            if p > 1:
+                re, im = e.permute_twiddle(re, im, p, self.k, self.c, role="unpack")
+        else:
+            re, im = e.fft_strided(re, im, self.n1, self.c)
+            re, im = self._exchange(re, im, "main")
+            # [p'][k][c] -> [k][p' C + c], twiddle w_N^((rank K + k)(p' C + c))
+            re, im = e.permute_twiddle(re, im, p, self.k, self.c, self.n, self.rank * self.k, role="unpack")
+        # 5. row transforms
         re, im = e.fft_rows(re, im, self.n2, self.k)
         if self.output_layout == "natural" and p > 1:
             # rank holds [K][N2] = X[k1 + N1 k2]; natural block q wants k2 in its block (N2/P values), all k1:
             # [K][P][C] -> chunks [P][K][C], exchange -> [P'][K][C] = [k1][c] for its k2 block, then
             # [k1 = N1][C] -> [C][N1] to make k1 the fast index.
-            re, im = e.permute_twiddle(re, im, self.k, p, self.c)
-            re, im = self._all_to_all(re), self._all_to_all(im)
+            re, im = e.permute_twiddle(re, im, self.k, p, self.c, role="pack_out")
+            re, im = self._exchange(re, im, "out")
             re, im = self._transpose_last(re, im, self.n1, self.c)
         elif self.output_layout == "natural":
             re, im = self._transpose_last(re, im, self.n1, self.c)
         return re, im
 
     def _transpose_last(self, re, im, rows, cols):
-        """[rows][cols] -> [cols][rows] (k1 becomes the fast index); pure data movement."""
-        def tr(t):
-            return t.reshape(rows, cols).t().contiguous().reshape(-1)
-
-        return tr(re), tr(im)
+        """[rows][cols] -> [cols][rows] (k1 becomes the fast index); pure data movement into buffers kept by this object."""
+        key = ("transpose", re.numel(), re.dtype, re.device)
+        out = self._recv.get(key)
+        if out is None:
+            out = (re.new_empty(re.shape), im.new_empty(im.shape))
+            self._recv[key] = out
+        for src, dst in ((re, out[0]), (im, out[1])):
+            dst.view(cols, rows).copy_(src.view(rows, cols).t())
+        return out

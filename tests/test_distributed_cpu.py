@@ -35,7 +35,16 @@ class NumpyEngine:
         z = self._c(re, im).reshape(batch, n)
         return self._split(np.fft.fft(z, axis=1) / n)
 
-    def permute_twiddle(self, re, im, a, b, c, n_tw=0, e0=0):
+    def supports_fourstep(self, n1, inner):
+        return n1 in (256, 512) and inner % 8 == 0          # (the GPU engine needs >= 64 columns; the logic is the same)
+
+    def fft_strided_fourstep(self, re, im, n1, inner, n_total, col0):
+        z = np.fft.fft(self._c(re, im).reshape(n1, inner), axis=0) / n1
+        k = np.arange(n1)[:, None]
+        col = col0 + np.arange(inner)[None, :]
+        return self._split(z * np.exp(-2j * np.pi * ((k * col) % n_total) / n_total))
+
+    def permute_twiddle(self, re, im, a, b, c, n_tw=0, e0=0, role=None):
         z = self._c(re, im).reshape(a, b, c).transpose(1, 0, 2)
         if n_tw:
             row = (e0 + np.arange(b))[:, None, None]
@@ -52,7 +61,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, in_layout, out_layout, ret):
+def _worker(rank, world, port, n, in_layout, out_layout, fused, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,7 +72,8 @@ def _worker(rank, world, port, n, in_layout, out_layout, ret):
         rng = np.random.default_rng(1234)            # same signal on every rank
         x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))
         xr, xi = x.real.astype(np.float16), x.imag.astype(np.float16)
-        f = DistributedFFT1D(n, engine=NumpyEngine(), input_layout=in_layout, output_layout=out_layout)
+        f = DistributedFFT1D(n, engine=NumpyEngine(), input_layout=in_layout, output_layout=out_layout, fused=fused)
+        assert f.fused == fused
         idx = f.input_indices()
         re, im = f.forward(torch.from_numpy(xr[idx].copy()), torch.from_numpy(xi[idx].copy()))
         exact = np.fft.fft(xr.astype(np.float64) + 1j * xi.astype(np.float64)) / n
@@ -79,18 +89,23 @@ def _worker(rank, world, port, n, in_layout, out_layout, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,in_layout,out_layout", [
-    (2, 1 << 10, "columns", "transposed"),
-    (2, 1 << 13, "columns", "transposed"),
-    (4, 1 << 12, "columns", "transposed"),
-    (2, 1 << 12, "natural", "transposed"),
-    (2, 1 << 12, "columns", "natural"),
-    (4, 1 << 14, "natural", "natural"),
+@pytest.mark.parametrize("world,n,in_layout,out_layout,fused", [
+    (2, 1 << 10, "columns", "transposed", False),
+    (2, 1 << 13, "columns", "transposed", False),
+    (4, 1 << 12, "columns", "transposed", False),
+    (2, 1 << 12, "natural", "transposed", False),
+    (2, 1 << 12, "columns", "natural", False),
+    (4, 1 << 14, "natural", "natural", False),
+    # fused form: N1 = 256, the four-step twiddle applied by the column pass, the unpack a pure re-order
+    (2, 1 << 13, "columns", "transposed", True),
+    (4, 1 << 14, "columns", "transposed", True),
+    (4, 1 << 16, "natural", "natural", True),
+    (2, 1 << 15, "natural", "transposed", True),
 ])
-def test_distributed_fft_over_gloo(world, n, in_layout, out_layout):
+def test_distributed_fft_over_gloo(world, n, in_layout, out_layout, fused):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, in_layout, out_layout, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, in_layout, out_layout, fused, ret), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
         err, partition_ok = ret[rank]
@@ -107,9 +122,9 @@ def test_single_rank_layouts():
     rng = np.random.default_rng(5)
     xr, xi = rng.uniform(-1, 1, n).astype(np.float16), rng.uniform(-1, 1, n).astype(np.float16)
     exact = np.fft.fft(xr.astype(np.float64) + 1j * xi.astype(np.float64)) / n
-    for out_layout in ("transposed", "natural"):
-        f = DistributedFFT1D(n, engine=NumpyEngine(), input_layout="natural", output_layout=out_layout)
-        assert np.array_equal(f.input_indices(), np.arange(n))
+    for out_layout, fused in (("transposed", False), ("natural", False), ("transposed", True), ("natural", True)):
+        f = DistributedFFT1D(n, engine=NumpyEngine(), input_layout="natural", output_layout=out_layout, fused=fused)
+        assert np.array_equal(f.input_indices(), np.arange(n)) and f.fused == fused and (not fused or f.n1 == 256)
         re, im = f.forward(torch.from_numpy(xr.copy()), torch.from_numpy(xi.copy()))
         got = re.numpy().astype(np.float64) + 1j * im.numpy().astype(np.float64)
         want = exact[f.output_indices()]

@@ -52,16 +52,21 @@ def test_permute_twiddle_kernel(tf, a, b, c, n_tw, e0):
                                                              o_im.data_ptr(), a, b, 12, 0, 0, 0))
 
 
-@pytest.mark.parametrize("lg,out_layout", [(12, "transposed"), (16, "transposed"), (20, "transposed"), (20, "natural"),
-                                           (22, "natural"), (23, "transposed")])
-def test_driver_with_hip_engine_single_rank(tf, orc, lg, out_layout):
+@pytest.mark.parametrize("lg,out_layout,fused", [(12, "transposed", False), (16, "transposed", False), (20, "transposed", False),
+                                                 (20, "natural", False), (22, "natural", False), (23, "transposed", False),
+                                                 (14, "transposed", True), (16, "transposed", True), (20, "transposed", True),
+                                                 (21, "transposed", True), (21, "natural", True), (24, "transposed", True)])
+def test_driver_with_hip_engine_single_rank(tf, orc, lg, out_layout, fused):
+    """General form (balanced split, fused re-order + twiddle kernel) and fused form (one radix-256 / 512 column pass
+    that applies the four-step twiddle itself) against the CPU oracle."""
     import torch
     from tensor_fft_amd.distributed import DistributedFFT1D, HipEngine
 
     n = 1 << lg
     rng = np.random.default_rng(lg)
     xr, xi = rng.uniform(-1, 1, n).astype(np.float16), rng.uniform(-1, 1, n).astype(np.float16)
-    f = DistributedFFT1D(n, engine=HipEngine(0), input_layout="natural", output_layout=out_layout)
+    f = DistributedFFT1D(n, engine=HipEngine(0), input_layout="natural", output_layout=out_layout, fused=fused)
+    assert f.fused == fused and (not fused or f.n1 in (256, 512))
     re, im = f.forward(torch.from_numpy(xr).cuda(), torch.from_numpy(xi).cuda())
     torch.cuda.synchronize()
     exact = _c(*orc.dft64(xr, xi))[0]
@@ -69,3 +74,36 @@ def test_driver_with_hip_engine_single_rank(tf, orc, lg, out_layout):
     want = exact[f.output_indices()]
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     assert rel < 1.5e-3, rel
+    # second call reuses every buffer (nothing is allocated per step) and gives the same bits
+    keep_re = re.clone()
+    ptr = re.data_ptr()
+    re2, _ = f.forward(torch.from_numpy(xr).cuda(), torch.from_numpy(xi).cuda())
+    torch.cuda.synchronize()
+    assert re2.data_ptr() == ptr and bool((re2 == keep_re).all())
+
+
+def test_single_gpu_2pow26_against_oracle(tf, orc):
+    """BASELINE configs[4b] length on one GPU (world size 1): N = 2^26 = 256 x 2^18 through the fused four-step path
+    (what each of 8 ranks would run around the exchange), full spectrum against the CPU oracle's fp64 FFT."""
+    import torch
+    from tensor_fft_amd.distributed import DistributedFFT1D, HipEngine
+
+    n = 1 << 26
+    xr, xi = orc.synth_uniform(n, 1, 0, 26)
+    f = DistributedFFT1D(n, engine=HipEngine(0), input_layout="columns", output_layout="transposed")
+    assert f.fused and f.n1 * f.n2 == n
+    re, im = f.forward(torch.from_numpy(xr[0]).cuda(), torch.from_numpy(xi[0]).cuda())
+    torch.cuda.synchronize()
+    e_re, e_im = orc.dft64(xr, xi)
+    want = (e_re[0] + 1j * e_im[0]).reshape(f.n2, f.n1).T.reshape(-1)          # X[k1 + N1 k2] stored [k1][k2]
+    got = _c(re.cpu().numpy(), im.cpu().numpy())
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel < 1.5e-3, rel
+    # the library's own single-GPU plan of the same length agrees
+    dev = torch.from_numpy(np.concatenate([xr[0], xi[0]])).cuda()
+    out = torch.empty_like(dev)
+    tf.TfftPlan(n, 1, 0, preserve_input=True).exec(dev, dev[n:], out, out[n:])
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().astype(np.float64)
+    nat = o[:n] + 1j * o[n:]
+    assert np.linalg.norm(nat - (e_re[0] + 1j * e_im[0])) / np.linalg.norm(want) < 1.5e-3
