@@ -951,7 +951,7 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   if (!single_kernel(p)) {
     const uint64_t tn = tw4 ? tw4 : n;          // modulus of the w tables
     const uint64_t lo_n = std::min<uint64_t>(tn, stockham::kTwLoSize);
-    const uint64_t hi_n = tn > stockham::kTwLoSize ? tn / stockham::kTwLoSize : 0;
+    const uint64_t hi_n = tn > stockham::kTwLoSize ? tn / stockham::kTwLoSize : 1;   // entry 0 = 1 + 0 i always exists
     std::vector<float2> lo(lo_n), hi(hi_n);
     for (uint64_t t = 0; t < lo_n; ++t) {
       const double a = -2.0 * M_PI * static_cast<double>(t) / static_cast<double>(tn);

@@ -1,0 +1,22 @@
+#!/bin/bash
+# rocprofv3 evidence for the headline benchmark, from the SAME command the driver runs (python3 bench.py):
+#   kernel trace + stats of a default run, then PMC counters in separate passes (FETCH_SIZE and WRITE_SIZE cannot share
+#   one; never --pmc together with a trace domain).   usage: tools/profile_bench.sh TAG
+# Output under gpurun_out/; fold with:  python tools/summarize_pmc.py TAG fft4096_kernel --dirs "gpurun_out/pmc_TAG_bench_*" \
+#   --trace "gpurun_out/trace_TAG_bench/*kernel_stats.csv" --alg-bytes 2147483648
+set -eo pipefail
+TAG=$1
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_${TAG}_bench -o t -- python3 bench.py --no-cpu-baseline --no-other-configs > $OUT/trace_${TAG}_bench.log 2>&1
+echo "trace done"
+i=0
+for SET in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM"; do
+  i=$((i+1))
+  rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_${TAG}_bench_$i -o p -- python3 bench.py --no-cpu-baseline --no-other-configs --steps 3 --warmup 1 > $OUT/pmc_${TAG}_bench_$i.log 2>&1
+  echo "pmc set $i done"
+done
