@@ -707,8 +707,6 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
 
   uint8_t* const img = lds + kLdsTable;
   uint8_t* const img_q = img + seq * kHalf;
-  const uint32_t img_q_off = __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)img_q)));
   const uint8_t* const g_tab = lds + lane * 16;
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, x = lane & 15;
   const int ihi = 4 * g + q;
@@ -728,10 +726,24 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     for (int r = 0; r < 4; ++r) c_base[r] = lookup_n(a, (16 * ((MODE == kColsOnLanes) ? (4 * g + r) : x)) * n512);
     c_step = lookup_n(a, n512);
   }
+  // (operands of the statement: the compiler has these constants in registers HERE and knows their loads have landed;
+  // otherwise their first use, inside the loop, waits on whatever vector-memory operation is youngest by then)
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(c_base[0].re), "+v"(c_base[0].im), "+v"(c_base[1].re), "+v"(c_base[1].im), "+v"(c_base[2].re),
+                 "+v"(c_base[2].im), "+v"(c_base[3].re), "+v"(c_base[3].im), "+v"(c_step.re), "+v"(c_step.im)
+               :
+               : "memory");
 
-  for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+  // Copy-in through registers: lane l of wave instruction i loads the 16 bytes that belong at LDS byte
+  // 8192 w4 + 1024 i + 16 l of its sequence's (swizzled) half-image. The loads of block n + 1 are issued behind barrier C of
+  // block n (stage 2 has consumed its operands, 64 registers are free) and fly under the fp32 read-out, the stores and
+  // barrier D; they are written to LDS at the top of the next iteration. The workgroup fills the CU's LDS, so nothing
+  // else can overlap its HBM reads with its arithmetic (the LDS-DMA version started the copy-in after barrier D and
+  // waited for it: 42 % of the wave time parked, profiles/r2_c3_pmc_summary.json).
+  u4 raw_re[8], raw_im[8];
+  auto issue_loads = [&](uint32_t blk) {
     const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;
-    const uint64_t bidx = gc0 >> pshift;                     // pitch >= 64: one batch entry per block
+    const uint64_t bidx = gc0 >> pshift;
     const uint64_t mb = gc0 & (a.pitch - 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -740,24 +752,22 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       const uint32_t r = sr * kRps + v / kCpr;               // row of the sequence's 256-row image
       const uint32_t chunk = v % kCpr;
       const uint64_t off = ((2 * r + seq) * a.pitch + mb + 8 * chunk) * 2;
-      const uint8_t* gr = reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off;
-      const uint8_t* gi = reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off;
-      const uint32_t d0 = img_q_off + 8192 * w4 + 1024 * i, d1 = d0 + kPlaneAll;
-      uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\t"
-          "s_mov_b32 m0, %3\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off nt\n\t"
-          "s_mov_b32 m0, %4\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %2, off nt\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
-          : "memory");
+      raw_re[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off));
+      raw_im[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if (blockIdx.x < total) issue_loads(blockIdx.x);
+
+  for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;
+    const uint64_t bidx = gc0 >> pshift;                     // pitch >= 64: one batch entry per block
+    const uint64_t mb = gc0 & (a.pitch - 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      *reinterpret_cast<u4*>(img_q + 8192 * w4 + 1024 * i + 16 * lane) = raw_re[i];
+      *reinterpret_cast<u4*>(img_q + kPlaneAll + 8192 * w4 + 1024 * i + 16 * lane) = raw_im[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // A: both half-images are in LDS
 
     // ---- stage 1
@@ -857,6 +867,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // C: A_0 and A_1 are complete
+    if (blk + gridDim.x < total) issue_loads(blk + gridDim.x);     // the next block's input starts flying now
 
     if (MODE == kColsOnLanes) {
       // ---- radix-2 combine at read-out: 16-byte chunks = 8 consecutive k of one column; a column's 512 outputs are
