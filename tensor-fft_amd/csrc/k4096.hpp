@@ -64,7 +64,8 @@ constexpr int kOffTw = 2048;     // 64 lanes x {float re[4], float im[4]}
 constexpr int kOffG = 4096;      // 16 tiles x 64 lanes x 8 halfs (RE-form)
 constexpr int kOffH = kOffG + 16384;
 constexpr int kOffF1n = kOffH + 16384;   // as kOffF1 but slots in natural order (column-pass kernel)
-constexpr int kTableBytes = kOffF1n + 2048;
+constexpr int kOffWR = kOffF1n + 2048;   // radix-R front end of k4096r.hpp as an MFMA A operand: R = 2, 4, 8 -> 3 x 64 lanes x 8 B
+constexpr int kTableBytes = kOffWR + 3 * 512;
 
 // Contraction slot (lane group g, j) of stage 1 holds n2 = sigma(g, j): even rows
 // for lanes 0-31, odd rows for lanes 32-63, so that each 32-lane half of a
@@ -147,6 +148,24 @@ inline void build_tables(std::vector<uint8_t>& blob, const TableScale ts = Table
       cexp(static_cast<long>(4 * g + r) * x, 256, c, s);
       put_f(kOffTw + lane * 32 + 4 * r, c * ts.tw);
       put_f(kOffTw + lane * 32 + 16 + 4 * r, s * ts.tw);
+    }
+    // Radix-R butterfly of k4096r.hpp as a 16 x 16 real matrix (A operand of v_mfma_f32_16x16x16_f16: lane = row, 4 k-slots
+    // per lane group). Rows rho' = 2R h' + 2 s2 + pl' (output s2, plane pl'), columns rho = 2R h + R pl + i (block i, plane
+    // pl); h, h' < 8 / R number the independent column sets that share one product (block diagonal). Entry = the real
+    // 2 x 2 form of w_R^(i s2) / (2 R): the 1 / (2 R) is the front end's scaling incl. its factor 1/2 of headroom.
+    for (int lr = 0; lr < 3; ++lr) {
+      const int R = 2 << lr;
+      for (int j = 0; j < 4; ++j) {
+        const int rp = x, rho = 4 * g + j;
+        const int hp = rp / (2 * R), s2 = (rp % (2 * R)) >> 1, plp = rp & 1;
+        const int h = rho / (2 * R), pl = (rho % (2 * R)) / R, i = rho % R;
+        double c, sn, v = 0.0;
+        cexp(static_cast<long>(i) * s2, R, c, sn);
+        c /= 2.0 * R;
+        sn /= 2.0 * R;
+        if (h == hp) v = (plp == 0) ? (pl == 0 ? c : -sn) : (pl == 0 ? sn : c);
+        put_h(kOffWR + lr * 512 + lane * 8 + 2 * j, v);
+      }
     }
     for (int k0 = 0; k0 < 16; ++k0)
       for (int j = 0; j < 4; ++j) {

@@ -78,7 +78,6 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
 
   // ---- constant of the radix-R front end: w_N^1 (v_cos / v_sin take revolutions; their ~1e-6 absolute error is three
   // orders below binary16's resolution)
-  const float st_re = __builtin_amdgcn_cosf(1.0f / kN), st_im = -__builtin_amdgcn_sinf(1.0f / kN);
 
   const uint32_t out_chunk = 4096u * s;     // this wave stores halves [4096 s, 4096 (s + 1)) of each output plane
 
@@ -86,31 +85,47 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   const uint32_t groups_total = ROWS ? batch : (batch + kGroups - 1) / kGroups;
   constexpr int kPs = 8 / R;                 // 16-byte chunks per lane, block and plane that this wave owns
 
-  // Raw samples of one iteration: this wave's chunk positions of all R blocks, both planes, straight from HBM into
-  // registers (16 x global_load_dwordx4, 1 KiB per wave instruction, non-temporal). The loads of iteration i + 1 are
-  // issued as soon as the front end of iteration i has consumed these registers, so they fly under the three MFMA
-  // stages, the read-out and the stores of iteration i: the kernel never sits waiting for its input with nothing
-  // else to do, which is what the LDS-DMA version did between its barriers D and A (one 160-KiB workgroup per CU,
-  // 3.6-3.9 TB/s; PMC: 35 % of the wave time parked in s_waitcnt / s_barrier).
-  u4 raw_r[kPs][R], raw_i[kPs][R];
+  // Raw samples of one iteration, straight from HBM into registers, already in the shape of MFMA B operands: the
+  // radix-R butterfly is a 16 x 16 x 16 product  U[rho'][column] = W[rho'][rho] X[rho][column]  with rho = (column set h,
+  // plane, block i) and rho' = (column set h, output s, plane) (k4096::build_tables, kOffWR). Lane (g, n) supplies k-slots
+  // rho = 4 g + jj for column n of a tile, so it loads, for j < 4 and jj < 4, the 16-byte chunk 64 (s kPs + h) + n + 16 j of
+  // block i, plane pl: 8 consecutive columns e of 4 rows. Tile (j, e) takes element e of those four registers (two
+  // v_perm_b32). A wave instruction is four 256-byte segments. The loads of iteration i + 1 are issued as soon as the
+  // front end of iteration i has consumed these registers and fly under the three MFMA stages, the read-out and the
+  // stores of iteration i (the LDS-DMA version of round 1 started its copy-in after the last barrier and waited for it:
+  // one 160-KiB workgroup per CU, 3.6-3.9 TB/s, 35 % of the wave time parked in s_waitcnt / s_barrier).
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const int fg = lane >> 4, fn = lane & 15;
+  u4 raw[4][4];
   auto issue_loads = [&](uint32_t it) {
     const uint32_t b_raw = ROWS ? (it >> 9) : it * kGroups + grp;
     const uint32_t b = (ROWS || b_raw < batch) ? b_raw : batch - 1;     // past the end: re-read the last transform
     const uint32_t r0 = it & 511;
-    const uint16_t* const base_re = in_re + in_map.off(b) + (ROWS ? static_cast<uint64_t>(r0) * 4096 : 0);
-    const uint16_t* const base_im = in_im + in_map.off(b) + (ROWS ? static_cast<uint64_t>(r0) * 4096 : 0);
-    constexpr uint64_t kBlockStep = ROWS ? 512ull * 4096 : 4096ull;     // block r of the group: rows r0 + 512 r, or samples 4096 r
+    const uint64_t base = in_map.off(b) + (ROWS ? static_cast<uint64_t>(r0) * 4096 : 0);
+    constexpr uint64_t kBlockStep = ROWS ? 512ull * 4096 : 4096ull;     // block i of the group: rows r0 + 512 i, or samples 4096 i
 #pragma unroll
-    for (int ps = 0; ps < kPs; ++ps) {
-      const uint32_t chunk = 64u * (s * kPs + ps) + lane;
+    for (int jj = 0; jj < 4; ++jj) {
+      const int rho = 4 * fg + jj;
+      const int h = rho / (2 * R), pl = (rho % (2 * R)) / R, i = rho % R;
+      const uint16_t* const src = (pl ? in_im : in_re) + base + kBlockStep * i + 8u * (64u * (s * kPs + h) + fn);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        raw_r[ps][r] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(base_re + kBlockStep * r + 8 * chunk));
-        raw_i[ps][r] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(base_im + kBlockStep * r + 8 * chunk));
-      }
+      for (int j = 0; j < 4; ++j) raw[j][jj] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src + 128 * j));
     }
   };
   if (blockIdx.x < groups_total) issue_loads(blockIdx.x);
+
+  // output side of the front-end product: lane (g, n) holds rows rho' = 4 g + r: outputs s2a (r = 0, 1: re, im) and
+  // s2a + 1 (r = 2, 3) of column set h'
+  const int hq = (4 * fg) / (2 * R), s2a = ((4 * fg) % (2 * R)) >> 1;
+  const int mm_out = s * kPs + hq;                                       // 1-KiB block of the plane this lane writes
+  uint8_t* const reg_a = gl + s2a * kLdsWaveBytes + mm_out * 1024;
+  uint8_t* const reg_b = reg_a + kLdsWaveBytes;
+  const h4 w_op = *reinterpret_cast<const h4*>(tables + kOffWR + (R == 2 ? 0 : (R == 4 ? 512 : 1024)) + lane * 8);
+  // 1D: twiddle w_N^(m s2), m = 8 (64 mm + n + 16 j) + e: per-lane steps w_N^(s2) along e
+  const float sa_re = __builtin_amdgcn_cosf(static_cast<float>(s2a) * (1.0f / kN)),
+              sa_im = -__builtin_amdgcn_sinf(static_cast<float>(s2a) * (1.0f / kN));
+  const float sb_re = __builtin_amdgcn_cosf(static_cast<float>(s2a + 1) * (1.0f / kN)),
+              sb_im = -__builtin_amdgcn_sinf(static_cast<float>(s2a + 1) * (1.0f / kN));
 
   for (uint32_t it = blockIdx.x; it < groups_total; it += gridDim.x) {
     // a group past the end of the batch re-does the last transform (it keeps the barriers uniform) without storing
@@ -119,75 +134,58 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     const uint32_t b = live ? b_raw : batch - 1;
     const uint32_t r0 = it & 511;
 
-    // ---- radix-R front end, registers -> the group's R LDS regions: this wave owns 8 / R chunks per lane (16 bytes =
-    // 8 consecutive m) of every block, so each sample is read once and each u_s[m] written once. Region s ends up
-    // holding u_s in the 4096 kernel's (swizzled) image.
+    // ---- radix-R front end on the matrix pipe: 32 tiles of 16 columns per wave. u_s[m] = w_N^(m s) / (2 R) sum_i x_i[m] w_R^(i s)
+    // (2D rows: the scalar w_4096^(r0 s) instead of w_N^(m s)), rounded once to binary16 and written to region s in the
+    // 4096 kernel's swizzled image: a lane's 8 tiles e of one j are the 8 columns of one 16-byte chunk.
 #pragma unroll
-    for (int ps = 0; ps < kPs; ++ps) {
-      const int mm = s * kPs + ps;                                   // 1-KiB block of the plane: chunks 64 mm .. 64 mm + 63
-      const uint32_t slot = mm * 1024 + 16 * (lane ^ (2 * mm));      // LDS slot of global chunk c = 64 mm + lane
-      // w_N^m, m = m0 + e (1D) or the per-iteration scalar w_4096^r0 (2D rows)
-      const float rev0 = ROWS ? static_cast<float>(r0) * (1.0f / 4096) : static_cast<float>(8 * (64 * mm + lane)) * (1.0f / kN);
-      float w1_re = __builtin_amdgcn_cosf(rev0), w1_im = -__builtin_amdgcn_sinf(rev0);
-      // (plain dword arrays: __builtin_bit_cast applied directly to an element of an ext-vector reads element 0)
-      uint32_t in_r[R][4], in_i[R][4];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const u4 vr = raw_r[ps][r];
-        const u4 vi = raw_i[ps][r];
-        in_r[r][0] = vr.x; in_r[r][1] = vr.y; in_r[r][2] = vr.z; in_r[r][3] = vr.w;
-        in_i[r][0] = vi.x; in_i[r][1] = vi.y; in_i[r][2] = vi.z; in_i[r][3] = vi.w;
+    for (int j = 0; j < 4; ++j) {
+      float ta_re, ta_im, tb_re, tb_im;                               // twiddles of outputs s2a, s2a + 1 at e = 0
+      if (ROWS) {
+        const float ra = static_cast<float>((r0 * s2a) & 4095) * (1.0f / 4096), rb = static_cast<float>((r0 * (s2a + 1)) & 4095) * (1.0f / 4096);
+        ta_re = __builtin_amdgcn_cosf(ra); ta_im = -__builtin_amdgcn_sinf(ra);
+        tb_re = __builtin_amdgcn_cosf(rb); tb_im = -__builtin_amdgcn_sinf(rb);
+      } else {
+        const uint32_t m0 = 8u * (64u * mm_out + fn + 16u * j);
+        float ra = static_cast<float>((m0 * s2a) & (kN - 1)) * (1.0f / kN), rb = static_cast<float>((m0 * (s2a + 1)) & (kN - 1)) * (1.0f / kN);
+        // (these twiddles do not depend on the iteration: left alone, the compiler hoists all 32 tiles' worth of them out
+        // of the loop, 128 floats, and spills them; the empty statement makes the angles opaque here)
+        asm volatile("" : "+v"(ra), "+v"(rb));
+        ta_re = __builtin_amdgcn_cosf(ra); ta_im = -__builtin_amdgcn_sinf(ra);
+        tb_re = __builtin_amdgcn_cosf(rb); tb_im = -__builtin_amdgcn_sinf(rb);
       }
-      uint32_t o_r[R][4], o_i[R][4];
+      uint32_t oa_re[4], oa_im[4], ob_re[4], ob_im[4];
+      float ka_re = 0.f, ka_im = 0.f, kb_re = 0.f, kb_im = 0.f;       // even column waiting for its odd partner
 #pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {        // two samples (one dword of each plane) at a time
-        float ur[2][R], ui[2][R];
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+        uint32_t d0[4];
 #pragma unroll
-        for (int lo = 0; lo < 2; ++lo) {
-          stockham::cf v[R];
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const h2 hr = __builtin_bit_cast(h2, in_r[r][e2]), hi = __builtin_bit_cast(h2, in_i[r][e2]);
-            v[r] = stockham::cf{static_cast<float>(hr[lo]), static_cast<float>(hi[lo])};
-          }
-          stockham::dft<R>(v);
-          // u_s = v[s] w_N^(s m) / (2 R): powers of w1 = w_N^m, the factor 1 / (2 R) riding on them
-          float pw_re = w1_re * (0.5f / R), pw_im = w1_im * (0.5f / R);
-          ur[lo][0] = v[0].re * (0.5f / R);
-          ui[lo][0] = v[0].im * (0.5f / R);
-#pragma unroll
-          for (int s2 = 1; s2 < R; ++s2) {
-            const float xr = v[s2].re, xi = v[s2].im;
-            ur[lo][s2] = __builtin_fmaf(xr, pw_re, -(xi * pw_im));
-            ui[lo][s2] = __builtin_fmaf(xr, pw_im, xi * pw_re);
-            if (s2 + 1 < R) {
-              const float nr = __builtin_fmaf(pw_re, w1_re, -(pw_im * w1_im));
-              const float ni = __builtin_fmaf(pw_re, w1_im, pw_im * w1_re);
-              pw_re = nr;
-              pw_im = ni;
-            }
-          }
-          if (!ROWS) {        // next sample: w_N^(m + 1)
-            // The recurrence does not depend on the data, so the scheduler would run all 8 samples' twiddle powers
-            // ahead (128 live floats for R = 8: 256 VGPRs and spills). Tie it to this sample's result (no instruction).
-            asm volatile("" : "+v"(w1_re), "+v"(w1_im) : "v"(ur[lo][R - 1]));
-            const float nr = __builtin_fmaf(w1_re, st_re, -(w1_im * st_im));
-            const float ni = __builtin_fmaf(w1_re, st_im, w1_im * st_re);
-            w1_re = nr;
-            w1_im = ni;
-          }
+        for (int jj = 0; jj < 4; ++jj) d0[jj] = (e >> 1) == 0 ? raw[j][jj].x : ((e >> 1) == 1 ? raw[j][jj].y : ((e >> 1) == 2 ? raw[j][jj].z : raw[j][jj].w));
+        const u2 bop = {__builtin_amdgcn_perm(d0[1], d0[0], sel), __builtin_amdgcn_perm(d0[3], d0[2], sel)};
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+        const f4 d = __builtin_amdgcn_mfma_f32_16x16x16f16(w_op, __builtin_bit_cast(h4, bop), z, 0, 0, 0);
+        const float ua_re = __builtin_fmaf(d[0], ta_re, -(d[1] * ta_im)), ua_im = __builtin_fmaf(d[0], ta_im, d[1] * ta_re);
+        const float ub_re = __builtin_fmaf(d[2], tb_re, -(d[3] * tb_im)), ub_im = __builtin_fmaf(d[2], tb_im, d[3] * tb_re);
+        if ((e & 1) == 0) {
+          ka_re = ua_re; ka_im = ua_im; kb_re = ub_re; kb_im = ub_im;
+        } else {
+          oa_re[e >> 1] = pk(ka_re, ua_re); oa_im[e >> 1] = pk(ka_im, ua_im);
+          ob_re[e >> 1] = pk(kb_re, ub_re); ob_im[e >> 1] = pk(kb_im, ub_im);
         }
-#pragma unroll
-        for (int s2 = 0; s2 < R; ++s2) {
-          o_r[s2][e2] = pk(ur[0][s2], ur[1][s2]);
-          o_i[s2][e2] = pk(ui[0][s2], ui[1][s2]);
+        if (!ROWS && e < 7) {                                        // next column: w_N^((m + 1) s2)
+          const float na_re = __builtin_fmaf(ta_re, sa_re, -(ta_im * sa_im)), na_im = __builtin_fmaf(ta_re, sa_im, ta_im * sa_re);
+          const float nb_re = __builtin_fmaf(tb_re, sb_re, -(tb_im * sb_im)), nb_im = __builtin_fmaf(tb_re, sb_im, tb_im * sb_re);
+          ta_re = na_re; ta_im = na_im; tb_re = nb_re; tb_im = nb_im;
         }
       }
-#pragma unroll
-      for (int s2 = 0; s2 < R; ++s2) {
-        *reinterpret_cast<u4*>(gl + s2 * kLdsWaveBytes + slot) = u4{o_r[s2][0], o_r[s2][1], o_r[s2][2], o_r[s2][3]};
-        *reinterpret_cast<u4*>(gl + s2 * kLdsWaveBytes + 8192 + slot) = u4{o_i[s2][0], o_i[s2][1], o_i[s2][2], o_i[s2][3]};
-      }
+      const uint32_t slot = 16u * ((fn + 16u * j) ^ (2u * mm_out));   // chunk n + 16 j of block mm_out, swizzled
+      *reinterpret_cast<u4*>(reg_a + slot) = u4{oa_re[0], oa_re[1], oa_re[2], oa_re[3]};
+      *reinterpret_cast<u4*>(reg_a + 8192 + slot) = u4{oa_im[0], oa_im[1], oa_im[2], oa_im[3]};
+      *reinterpret_cast<u4*>(reg_b + slot) = u4{ob_re[0], ob_re[1], ob_re[2], ob_re[3]};
+      *reinterpret_cast<u4*>(reg_b + 8192 + slot) = u4{ob_im[0], ob_im[1], ob_im[2], ob_im[3]};
+      // keep the scheduler from pulling the next chunk's 8 products (32 accumulator registers) and twiddle chains up here:
+      // with all 32 tiles in one scheduling region it spills
+      __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // B: u_0 .. u_(R-1) are complete
