@@ -159,15 +159,24 @@ def check_transforms(torch, orc, y, n, batch, ids, first_fft=0, seed=SEED, perm=
 
 def other_configs(torch, tf, orc, device):
     """Short measurements of the other BASELINE configs and neighbouring lengths on the same GPU, after the headline
-    timing (not part of `value`): Gsamples/s over 10 back-to-back executions each, inputs resident, workspace preset,
+    timing (not part of `value`): Gsamples/s over 10 back-to-back executions each (after a ~50 ms clock ramp), inputs resident, workspace preset,
     and an oracle check of a sampled transform (or image) of what was just computed."""
     import numpy as np
 
     out = {}
 
     def timed(fn, reps=10):
-        for _ in range(3):
+        # the GPU has idled through the previous entry's CPU-side oracle check: ramp its clock for ~50 ms first (the
+        # headline measurement does the same with its RAMP launches), then time >= 10 launches
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_warm = 0
+        while time.perf_counter() - t0 < 0.05 or n_warm < 3:
             fn()
+            n_warm += 1
+            if n_warm % 8 == 0:
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
