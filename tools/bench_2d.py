@@ -12,8 +12,10 @@ re = ((torch.rand(b * n * n, device="cuda") * 2 - 1)).half(); im = ((torch.rand(
 o_re, o_im = torch.empty_like(re), torch.empty_like(im)
 plan = tf.TfftPlan2D(n, n, b, 0)
 ws = torch.empty(plan.workspace_bytes // 2, dtype=torch.float16, device="cuda"); plan.set_workspace(ws)
-for _ in range(2): plan.exec(re, im, o_re, o_im)
-torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.06:          # clock ramp
+    plan.exec(re, im, o_re, o_im); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(5): plan.exec(re, im, o_re, o_im)
