@@ -1,87 +1,68 @@
-// example_batch_fft.cpp — a batch of transforms through the reference's host interface, in the order the reference's own
-// batch example makes its calls (src/testing/ExampleBatchFFT.cu:20-85): CreatePlan(fft_length) with the default mode ->
-// PlanWorksOnDevice -> DataBatchHandler(fft_length, batch_size) -> PeakAtLastError -> CopyDataHostToDevice ->
-// ComputeFFT(plan, handler, GetMaxNoOptInSharedMem(device)) -> CopyResultsDeviceToHost(data, plan.results_in_results_)
-// -> device synchronise. Only the include line and the signal differ from a program written against the reference's
-// src/base headers: here each batch entry is one complex tone exp(+2 pi i f_b n / N) of amplitude 1/2, whose scaled
-// spectrum is 1/2 at bin f_b and zero elsewhere, so the program can check itself (exit code 0 = all entries right).
-#include <cassert>
+// example_batch_fft.cpp — a batch of transforms through the reference's host interface, with the calls in the order the
+// reference's batch example makes them (src/testing/ExampleBatchFFT.cu:20-85):
+//   CreatePlan(N)  ->  PlanWorksOnDevice  ->  DataBatchHandler(N, batch)  ->  PeakAtLastError  ->  CopyDataHostToDevice
+//   ->  ComputeFFT(plan, handler, GetMaxNoOptInSharedMem(device))  ->  CopyResultsDeviceToHost(data, results_in_results_)
+// A program written against src/base/{Plan,DataHandler,ComputeFFT}.h needs only its include line changed to build
+// against include/tensor_fft.hpp. Unlike the reference's example this one checks itself: batch entry b is the complex
+// tone 0.5 exp(+2 pi i f_b n / N), whose scaled spectrum is 0.5 at bin f_b and zero elsewhere (exit code 0 = all right).
 #include <cmath>
-#include <iostream>
-#include <memory>
+#include <cstdio>
 #include <optional>
 #include <string>
+#include <vector>
 
 #include "tensor_fft.hpp"
 
-int main() {
-  constexpr int fft_length = 16 * 16 * 16;
-  constexpr int batch_size = 20;
+namespace {
+constexpr int kN = 16 * 16 * 16;
+constexpr int kBatch = 20;
+int tone_of(int b) { return 3 + 7 * b; }
 
-  std::unique_ptr<__half[]> data(new __half[2 * static_cast<size_t>(fft_length) * batch_size]);
-  for (int b = 0; b < batch_size; ++b) {
-    const int f = 3 + 7 * b;
-    __half* re = data.get() + 2 * static_cast<size_t>(fft_length) * b;
-    __half* im = re + fft_length;
-    for (int n = 0; n < fft_length; ++n) {
-      const double ph = 2.0 * M_PI * static_cast<double>((static_cast<long>(f) * n) % fft_length) / fft_length;
-      re[n] = __float2half(static_cast<float>(0.5 * std::cos(ph)));
-      im[n] = __float2half(static_cast<float>(0.5 * std::sin(ph)));
+bool failed(const std::optional<std::string>& e, const char* what) {
+  if (e) std::printf("%s: %s\n", what, e->c_str());
+  return e.has_value();
+}
+}  // namespace
+
+int main() {
+  std::vector<__half> host(2 * static_cast<size_t>(kN) * kBatch);
+  for (int b = 0; b < kBatch; ++b) {
+    __half* plane_re = host.data() + 2 * static_cast<size_t>(kN) * b;
+    __half* plane_im = plane_re + kN;
+    for (int t = 0; t < kN; ++t) {
+      const double phase = 2.0 * M_PI * static_cast<double>((static_cast<long>(tone_of(b)) * t) % kN) / kN;
+      plane_re[t] = __float2half(static_cast<float>(0.5 * std::cos(phase)));
+      plane_im[t] = __float2half(static_cast<float>(0.5 * std::sin(phase)));
     }
   }
 
-  std::optional<std::string> error_mess;
-
-  std::optional<Plan<int>> possible_plan = CreatePlan(fft_length);
-  Plan<int> my_plan;
-  if (possible_plan) {
-    my_plan = possible_plan.value();
-  } else {
-    std::cout << "Plan creation failed" << std::endl;
+  const std::optional<Plan<int>> maybe_plan = CreatePlan(kN);          // default mode and launch parameters
+  if (!maybe_plan) {
+    std::printf("Plan creation failed\n");
     return 1;
   }
+  Plan<int> plan = *maybe_plan;
 
-  int device_id;
-  (void)hipGetDevice(&device_id);
-  assert((PlanWorksOnDevice(my_plan, device_id)));
+  int device = 0;
+  (void)hipGetDevice(&device);
+  if (!PlanWorksOnDevice(plan, device)) return 1;
 
-  DataBatchHandler my_handler(fft_length, batch_size);
-  error_mess = my_handler.PeakAtLastError();
-  if (error_mess) {
-    std::cout << error_mess.value() << std::endl;
-    return 1;
-  }
-
-  error_mess = my_handler.CopyDataHostToDevice(data.get());
-  if (error_mess) {
-    std::cout << error_mess.value() << std::endl;
-    return 1;
-  }
-
-  error_mess = ComputeFFT(my_plan, my_handler, GetMaxNoOptInSharedMem(device_id));
-  if (error_mess) {
-    std::cout << error_mess.value() << std::endl;
-    return 1;
-  }
-
-  error_mess = my_handler.CopyResultsDeviceToHost(data.get(), my_plan.results_in_results_);
-  if (error_mess) {
-    std::cout << error_mess.value() << std::endl;
-    return 1;
-  }
-
+  DataBatchHandler handler(kN, kBatch);                                // class template argument deduced, as in the reference
+  if (failed(handler.PeakAtLastError(), "allocation")) return 1;
+  if (failed(handler.CopyDataHostToDevice(host.data()), "host -> device")) return 1;
+  if (failed(ComputeFFT(plan, handler, GetMaxNoOptInSharedMem(device)), "ComputeFFT")) return 1;
+  if (failed(handler.CopyResultsDeviceToHost(host.data(), plan.results_in_results_), "device -> host")) return 1;
   (void)hipDeviceSynchronize();
 
   double worst = 0;
-  for (int b = 0; b < batch_size; ++b) {
-    const int f = 3 + 7 * b;
-    const __half* re = data.get() + 2 * static_cast<size_t>(fft_length) * b;
-    const __half* im = re + fft_length;
-    for (int k = 0; k < fft_length; ++k) {
-      worst = std::fmax(worst, std::fabs(__half2float(re[k]) - (k == f ? 0.5 : 0.0)));
+  for (int b = 0; b < kBatch; ++b) {
+    const __half* re = host.data() + 2 * static_cast<size_t>(kN) * b;
+    const __half* im = re + kN;
+    for (int k = 0; k < kN; ++k) {
+      worst = std::fmax(worst, std::fabs(__half2float(re[k]) - (k == tone_of(b) ? 0.5 : 0.0)));
       worst = std::fmax(worst, std::fabs(__half2float(im[k])));
     }
   }
-  std::cout << "batch of " << batch_size << " transforms of length " << fft_length << ": max |error| = " << worst << std::endl;
+  std::printf("batch of %d transforms of length %d: max |error| = %.3g\n", kBatch, kN, worst);
   return worst < 2e-3 ? 0 : 1;
 }
