@@ -265,7 +265,10 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       for (int r2 = 0; r2 < 4; ++r2) {
         // 16-byte slot 2 k1 + half of row 4g + r2 (512 B per row of 256 kk); plain layout: the interleaving
         // read-out below touches 2-, 4- or 8-byte pieces, so the 4096 kernel's slot swizzle is not used here
-        const uint32_t off = 16u * (2u * (lane & 15) + half) + 512u * (4 * g + r2);
+        // (R = 8, 1D: the 32-byte unit k1 of a row sits at unit k1 ^ s, so that the transposed read-out below, which
+        // takes the same 32 bytes from all 8 regions at once, finds them in 8 different bank groups)
+        const uint32_t k1s = (R == 8 && !ROWS) ? ((lane & 15) ^ s) : (lane & 15);
+        const uint32_t off = 16u * (2u * k1s + half) + 512u * (4 * g + r2);
         *reinterpret_cast<u4*>(wl + off) = u4{ore[r2][0], ore[r2][1], ore[r2][2], ore[r2][3]};
         *reinterpret_cast<u4*>(wl + 8192 + off) = u4{oim[r2][0], oim[r2][1], oim[r2][2], oim[r2][3]};
       }
@@ -312,14 +315,25 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         vr = u4{(pa[0] & 0xffffu) | (pa[1] << 16), (pa[2] & 0xffffu) | (pa[3] << 16), (pa[0] >> 16) | (pa[1] & 0xffff0000u), (pa[2] >> 16) | (pa[3] & 0xffff0000u)};
         vi = u4{(pb[0] & 0xffffu) | (pb[1] << 16), (pb[2] & 0xffffu) | (pb[3] << 16), (pb[0] >> 16) | (pb[1] & 0xffff0000u), (pb[2] >> 16) | (pb[3] & 0xffff0000u)};
       } else {
-        uint32_t pa[8], pb[8];
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-          pa[s2] = *reinterpret_cast<const uint16_t*>(gl + s2 * kLdsWaveBytes + 2 * kk0);
-          pb[s2] = *reinterpret_cast<const uint16_t*>(gl + s2 * kLdsWaveBytes + 8192 + 2 * kk0);
-        }
-        vr = u4{pa[0] | (pa[1] << 16), pa[2] | (pa[3] << 16), pa[4] | (pa[5] << 16), pa[6] | (pa[7] << 16)};
-        vi = u4{pb[0] | (pb[1] << 16), pb[2] | (pb[3] << 16), pb[4] | (pb[5] << 16), pb[6] | (pb[7] << 16)};
+        // R = 8: X[8 kk + s'] for 64 consecutive kk. A transposed LDS read hands lane (group rg, x) the four halves
+        // U_s'[kk], s' = 4 (rg & 1) .. + 3, of kk = block start + x (rows = regions, columns = 16 consecutive kk = one
+        // 32-byte unit of each region): 8 of the 16 output bytes. Groups (0, 1) and (2, 3) read two kk blocks each
+        // and one v_permlane16_swap per dword gives every lane both halves of ITS kk: 2 reads + 2 swaps per vector
+        // instead of 16 two-byte reads and their packing.
+        const uint32_t rg = lane >> 4, region = 4 * (rg & 1) + ((lane >> 2) & 3);
+        const uint32_t kka = out_chunk / 8 + 64u * i + 32u * (rg >> 1);      // first kk of this group pair's block A
+        const uint8_t* const rb = gl + region * kLdsWaveBytes + 8 * (lane & 3);
+        auto unit = [&](uint32_t kk) { return 512u * (kk >> 8) + 32u * (((kk >> 4) & 15) ^ region); };
+        auto two = [&](const uint8_t* plane_base, u4& v) {
+          const s4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(plane_base + unit(kka)));
+          const s4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(plane_base + unit(kka + 16)));
+          const u2 a = __builtin_bit_cast(u2, t0), b2 = __builtin_bit_cast(u2, t1);
+          auto sx = __builtin_amdgcn_permlane16_swap(a.x, b2.x, false, false);
+          auto sy = __builtin_amdgcn_permlane16_swap(a.y, b2.y, false, false);
+          v = u4{sx[0], sy[0], sx[1], sy[1]};
+        };
+        two(rb, vr);
+        two(rb + 8192, vi);
       }
       if (live) {
         __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(f_out_re + 512 * i + 8 * lane));

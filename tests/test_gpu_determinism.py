@@ -23,7 +23,36 @@ def test_repeated_runs_of_the_column_plan_are_bit_identical(n, batch):
     _repeat(n, batch, 1, 16777216)
 
 
-def _repeat(n, batch, inner, variant):
+@pytest.mark.parametrize("n,batch", [(1 << 16, 64), (1 << 20, 8), (1 << 21, 4), (1 << 24, 1)])
+def test_repeated_runs_of_the_transposed_order_plan_are_bit_identical(n, batch):
+    """Column pass with the four-step twiddle (v_sin / v_cos recurrences) + grouped single-kernel pass."""
+    _repeat(n, batch, 1, 0, output_order="transposed")
+
+
+def test_repeated_runs_of_the_fused_2d_plan_are_bit_identical():
+    import torch
+    import __graft_entry__ as g
+
+    g.build()
+    import tensor_fft_amd as tf
+
+    n, batch = 4096, 4
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    re = (torch.rand(batch * n * n, device="cuda", generator=gen) * 2 - 1).half()
+    im = (torch.rand(batch * n * n, device="cuda", generator=gen) * 2 - 1).half()
+    plan = tf.TfftPlan2D(n, n, batch, 0)
+    ref = None
+    for _ in range(10):
+        o_re, o_im = torch.zeros_like(re), torch.zeros_like(im)
+        plan.exec(re, im, o_re, o_im)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (o_re, o_im)
+        else:
+            assert bool((o_re == ref[0]).all()) and bool((o_im == ref[1]).all())
+
+
+def _repeat(n, batch, inner, variant, **plan_kw):
     import torch
     import __graft_entry__ as g
 
@@ -32,7 +61,7 @@ def _repeat(n, batch, inner, variant):
 
     gen = torch.Generator(device="cuda").manual_seed(n + inner)
     x = (torch.rand(batch * 2 * n * inner, device="cuda", generator=gen) * 2 - 1).half()
-    plan = tf.TfftPlan(n, batch, 0, inner=inner, preserve_input=True, variant=variant)
+    plan = tf.TfftPlan(n, batch, 0, inner=inner, preserve_input=True, variant=variant, **plan_kw)
     ref = None
     for _ in range(25):
         y = torch.zeros_like(x)
