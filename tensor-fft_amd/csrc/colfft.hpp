@@ -669,14 +669,16 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
 // Radix-512 column pass (columns-in-registers form, Ns >= 64): rows i = 2 m + q. The two decimated sequences
 // q = 0, 1 are two radix-256 problems, handled by waves 0-3 and 4-7 of the workgroup exactly as the 4-wave
 // cooperative kernel above handles one (64 columns, 128-byte row segments, one 32-KiB half-image per plane and
-// sequence). The q = 1 half multiplies its stage-2 output by w_512^k (k = ka + 16 kb: a per-lane base times a
-// 16-step recurrence over ka, as for the inter-pass twiddles). Both halves leave A_q[k][column] in LDS; the read-out
+// sequence). The q = 1 half's stage-2 operand is G with the combine twiddle folded in, G'[ka][n1][kb] = w_512^(ka + 16 kb)
+// G_ka[n1][kb] (k4096::build_tables, kOffG512): one rounding of a constant instead of an fp32 multiply per output and a
+// 16-step recurrence in the half that is the workgroup's critical path. Both halves leave A_q[k][column] in LDS; the read-out
 // forms X[k] = A_0 + A_1, X[k + 256] = A_0 - A_1 in fp32, applies the next pass's input twiddles there (they depend
 // on the full output index), rounds once and stores two 128-byte row segments per lane group.
 // One pass over HBM for a radix the 160-KiB LDS could not hold as one 512-row image of 256-byte segments:
 // 2^17 = 256 x 512 and 2^26 = 256 x 512 x 512 take one pass fewer.
 // ---------------------------------------------------------------------------
-constexpr int kWg512LdsBytes = kLdsTable + 4 * WgGeom<4>::kPlane;   // 144 KiB
+constexpr int kTab512 = 2 * kLdsTable;                                  // G for the even sequence, G with w_512^k folded in for the odd one
+constexpr int kWg512LdsBytes = kTab512 + 4 * WgGeom<4>::kPlane;       // 160 KiB
 
 
 // Next-pass twiddles of the radix-512 read-out: v_sin / v_cos (absolute error ~1e-6, three orders below binary16's
@@ -698,16 +700,18 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = wave >> 2, w4 = wave & 3;   // decimated sequence q, wave within its half
-  for (int i = tid; i < kLdsTable / 16; i += kThreads)
+  for (int i = tid; i < kLdsTable / 16; i += kThreads) {
     reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(a.tables + kOffG)[i];
+    reinterpret_cast<u4*>(lds + kLdsTable)[i] = reinterpret_cast<const u4*>(a.tables + kOffG512)[i];
+  }
   const h8 f_re = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32);
   const h8 f_im = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32 + 16);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  uint8_t* const img = lds + kLdsTable;
+  uint8_t* const img = lds + kTab512;
   uint8_t* const img_q = img + seq * kHalf;
-  const uint8_t* const g_tab = lds + lane * 16;
+  const uint8_t* const g_tab = lds + seq * kLdsTable + lane * 16;   // this sequence's stage-2 operand
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, x = lane & 15;
   const int ihi = 4 * g + q;
   const uint8_t* tr_base[kRps];
@@ -716,24 +720,6 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     tr_base[h] = img_q + (16 / kRps) * ihi * 256 + 16 * ((h * kCpr + 2 * w4 + (p >> 1)) ^ (2 * (ihi & 7))) + 8 * (p & 1);
   const uint32_t pshift = static_cast<uint32_t>(__builtin_ctzll(a.pitch));
   const uint32_t total = static_cast<uint32_t>(((a.tasks / a.groups) << pshift) / G::kCols);
-  const uint64_t n512 = (a.n_mask + 1) >> 9;   // w_512 = w_N^(N / 512)
-  // combine twiddle of the odd sequence: w_512^(ka + 16 kb); kb = x (columns in registers) or 4 g + r (columns on lanes)
-  cpx c_base[4], c_step = {1.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) c_base[r] = cpx{1.f, 0.f};
-  if (seq == 1) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c_base[r] = lookup_n(a, (16 * ((MODE == kColsOnLanes) ? (4 * g + r) : x)) * n512);
-    c_step = lookup_n(a, n512);
-  }
-  // (operands of the statement: the compiler has these constants in registers HERE and knows their loads have landed;
-  // otherwise their first use, inside the loop, waits on whatever vector-memory operation is youngest by then)
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(c_base[0].re), "+v"(c_base[0].im), "+v"(c_base[1].re), "+v"(c_base[1].im), "+v"(c_base[2].re),
-                 "+v"(c_base[2].im), "+v"(c_base[3].re), "+v"(c_base[3].im), "+v"(c_step.re), "+v"(c_step.im)
-               :
-               : "memory");
-
   // Copy-in through registers: lane l of wave instruction i loads the 16 bytes that belong at LDS byte
   // 8192 w4 + 1024 i + 16 l of its sequence's (swizzled) half-image. The loads of block n + 1 are issued behind barrier C of
   // block n (stage 2 has consumed its operands, 64 registers are free) and fly under the fp32 read-out, the stores and
@@ -806,7 +792,6 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     // ---- stage 2, combine twiddle of the odd sequence, A_q -> LDS
     //   columns in registers: data as the A operand, lane = kb, registers = 4 adjacent columns; image rows = k
     //   columns on lanes:     data as the B operand, lane = column, registers = kb; image rows = columns (512 B of k)
-    cpx pw = {1.f, 0.f};
     float hold_re[4], hold_im[4];
     uint32_t acc_re[4][4], acc_im[4][4];
 #pragma unroll
@@ -822,17 +807,6 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       } else {
         e_re = mfma(dop, __builtin_bit_cast(h8, graw));
         e_im = mfma(dop, im_form(graw));
-      }
-      if (seq == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const cpx wt = cmul(c_base[r], pw);
-          const float vr = __builtin_fmaf(e_re[r], wt.re, -(e_im[r] * wt.im));
-          const float vi = __builtin_fmaf(e_re[r], wt.im, e_im[r] * wt.re);
-          e_re[r] = vr;
-          e_im[r] = vi;
-        }
-        pw = cmul(pw, c_step);
       }
       if (MODE == kColsInRegs) {
         const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};

@@ -23,6 +23,7 @@
 #include "k256r.hpp"
 #include "k4096r.hpp"
 #include "colfft.hpp"
+#include "colfft1024.hpp"
 #include "permute.hpp"
 #include "stockham.hpp"
 #include "synth.hpp"
@@ -56,7 +57,7 @@ inline int ilog2(uint64_t x) {
 constexpr int kVarK4096 = 1 | 2 | 8 | 16;
 constexpr int kVarDebug = 4 | 64 | 128 | 65536 | (15 << 8);
 constexpr int kVarTuner = kVarK4096 | 32 | 4096 | 8192 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 |
-                          8388608 | 16777216 | 67108864;
+                          8388608 | 16777216 | 33554432 | 67108864;
 inline bool debug_variants_enabled() {
   const char* e = std::getenv("TFFT_DEBUG_VARIANTS");
   return e && e[0] == '1' && e[1] == 0;
@@ -93,7 +94,7 @@ enum class PassKind { K4096, K4096R, K256, K256R, Col256, Stockham };
 
 struct Pass {
   PassKind kind;
-  int radix;          // K4096: 4096; K256: 256; K256R: N / 256; Col256: 256 or 512; Stockham: 2 .. 64
+  int radix;          // K4096: 4096; K256: 256; K256R: N / 256; Col256: 256, 512 or 1024; Stockham: 2 .. 64
   uint64_t ns;        // unflattened product of the radices before this pass
   bool tw_next;       // Col256: apply the next pass's input twiddles to the output
   bool skip_tw;       // Stockham: input twiddles were applied by the previous pass
@@ -177,29 +178,36 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
     if (col_ok) n256 = lg / 8;
     int rem = lg - 8 * n256;
     std::vector<int> radices(n256, 256);
-    // Radix-512 column passes where they save a whole pass (2^15 = 512 x 64, 2^17 = 256 x 512, 2^18 = 512 x 512,
-    // 2^23 = 256 x 512 x 64, 2^25, 2^26 = 256 x 512 x 512, 2^27 = 512^3): the split lg = 8 a + 9 b + t, t <= 7, with the
-    // fewest passes (a tail of t bits costs 0 / 1 / 2 passes for t = 0 / 1..6 / 7); ties go to the fewest radix-512
-    // passes (their row segments are 128 bytes, not 256). variant bit 8388608 turns them off.
+    // Radix-512 / radix-1024 column passes where they save a whole pass (2^15 = 512 x 64, 2^17 = 256 x 512, 2^18 = 512 x 512,
+    // 2^19 = 512 x 1024, 2^20 = 1024 x 1024, 2^23 = 256 x 512 x 64, 2^25, 2^26 = 256 x 512 x 512, 2^27 = 512^3, 2^28 =
+    // 512 x 512 x 1024 ...): the split lg = 8 a + 9 b + 10 c + t, t <= 7, with the fewest passes (a tail of t bits costs
+    // 0 / 1 / 2 passes for t = 0 / 1..6 / 7); ties go to the fewest radix-1024 passes, then the fewest radix-512 passes
+    // (their row segments are 128 bytes, not 256; the radix-1024 pass has eight workgroup barriers per tile).
+    // variant bit 8388608 turns the radix-512 passes off, 33554432 the radix-1024 passes.
     const bool use512 = col_ok && inner == 1 && lg >= 15 && !(variant & 8388608);
-    if (use512) {
+    const bool use1024 = col_ok && inner == 1 && lg >= 16 && !(variant & 33554432);
+    if (use512 || use1024) {
       auto tail_cost = [](int t) { return t == 0 ? 0 : (t <= 6 ? 1 : 2); };
-      int best_a = n256, best_b = 0, best_cost = n256 + tail_cost(rem);
-      for (int b = 1; b <= 3; ++b)
-        for (int a2 = 0; 8 * a2 + 9 * b <= lg; ++a2) {
-          const int t = lg - 8 * a2 - 9 * b;
-          if (t > 7) continue;
-          const int cost = a2 + b + tail_cost(t);
-          if (cost < best_cost) {
-            best_cost = cost;
-            best_a = a2;
-            best_b = b;
+      int best_a = n256, best_b = 0, best_c = 0, best_cost = n256 + tail_cost(rem);
+      for (int c = 0; c <= (use1024 ? 3 : 0); ++c)
+        for (int b = 0; b <= (use512 ? 3 : 0); ++b)
+          for (int a2 = 0; 8 * a2 + 9 * b + 10 * c <= lg; ++a2) {
+            if (b + c == 0) continue;
+            const int t = lg - 8 * a2 - 9 * b - 10 * c;
+            if (t > 7) continue;
+            const int cost = a2 + b + c + tail_cost(t);
+            if (cost < best_cost) {
+              best_cost = cost;
+              best_a = a2;
+              best_b = b;
+              best_c = c;
+            }
           }
-        }
-      n256 = best_a + best_b;               // column passes in total
+      n256 = best_a + best_b + best_c;      // column passes in total
       radices.assign(best_a, 256);
       radices.insert(radices.end(), best_b, 512);
-      rem = lg - 8 * best_a - 9 * best_b;
+      radices.insert(radices.end(), best_c, 1024);
+      rem = lg - 8 * best_a - 9 * best_b - 10 * best_c;
     }
     // n = 512 along a strided axis as ONE radix-512 column pass (variant bit 67108864; the second pass of the fused 2D plan)
     if (n == 512 && inner >= 64 && (variant & 67108864) && !force_stockham) {
@@ -223,7 +231,7 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
     for (size_t i = 0; i < radices.size(); ++i) {
       const int R = radices[i];
       const bool last = (i + 1 == radices.size());
-      if (R == 256 || R == 512) {
+      if (R >= 256) {
         const bool no_tw = variant & 128;   // debugging aid: WRONG results, timing/determinism only
         passes.push_back(Pass{PassKind::Col256, R, ns, !last && !no_tw, false, last ? 0 : radices[i + 1]});
       } else {
@@ -450,6 +458,25 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     a.n_over_t = p->n / t;
     a.inv_t = 1.0 / static_cast<double>(t);
     a.a_shift = static_cast<uint32_t>(ilog2(p->n / (static_cast<uint64_t>(ps.next_radix) * ps.ns * radix)));
+  }
+  if (radix == 1024) {
+    // (plan creation only emits this pass where the geometry fits: pitch, and ns_f unless it is 1, multiples of 64)
+    const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
+    if (a.ns_f == 1) {
+      if (ps.tw_next)
+        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
+      else
+        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
+    } else {
+      if (ps.tw_next)
+        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
+      else if (ps.scale != 1.0f)         // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out
+        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
+      else
+        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
+    }
+    return TFFT_OK;
   }
   if (radix == 512) {
     // plan creation only emits this pass where the geometry fits (pitch, and ns_f unless it is 1, multiples of 64)
@@ -782,9 +809,10 @@ int tfft_max_no_optin_shared_mem(int device_id) {
 namespace {
 
 // tfft_plan_opts.scale -> constant operands and per-pass factors (include/tfft.h, TFFT_SCALE_*). Sequential: 1/16 per
-// MFMA stage in F / G / H, 1/R per autosort pass, 1/2 in the radix-512 combine. None: all of them 1. Once: as none, and
+// MFMA stage in F / G / H, 1/R per autosort pass, 1/2 in the radix-512 combine, 1/4 in the radix-1024 pass's G_q. None: all
+// of them 1. Once: as none, and
 // the single factor 2^-once_log2 rides on the LAST fp32 multiply of the plan: the inter-stage twiddle block of a
-// single-kernel plan, the butterfly output of a final autosort pass, the combine of a final radix-512 pass, the
+// single-kernel plan, the butterfly output of a final autosort pass, the combine of a final radix-512 / radix-1024 pass, the
 // twiddles the pass in front of a final radix-256 column pass applies (or that pass's own four-step twiddle), and for
 // a lone radix-256 column pass, which has no fp32 multiply at all, the stage-2 matrix G (2^-8 keeps G's entries normal).
 int apply_scale_mode(tfft_plan* p, const InternalOpts& io, k4096::TableScale& ts, double& r_fa, double& r_fb, double& r_s) {
@@ -792,7 +820,7 @@ int apply_scale_mode(tfft_plan* p, const InternalOpts& io, k4096::TableScale& ts
   const double s16 = seq ? 1.0 / 16 : 1.0;
   const int once_log2 = io.once_log2 >= 0 ? io.once_log2 : ilog2(p->n);
   const double fin = p->scale_mode == TFFT_SCALE_ONCE ? std::ldexp(1.0, -once_log2) : 1.0;
-  ts = k4096::TableScale{s16, s16, s16, 1.0};
+  ts = k4096::TableScale{s16, s16, s16, 1.0, seq ? s16 / 4 : s16};
   r_fa = r_fb = s16;
   r_s = 1.0;
   if (io.rows2d) ts.tw = 2.0;                  // fused 2D row pass: the front end's headroom factor (k4096r.hpp)
@@ -806,12 +834,13 @@ int apply_scale_mode(tfft_plan* p, const InternalOpts& io, k4096::TableScale& ts
   for (Pass& ps : p->passes) {
     ps.tw_scale = 1.0f;
     if (ps.kind == PassKind::Stockham) ps.scale = seq ? 1.0f / ps.radix : 1.0f;
+    else if (ps.radix == 1024) ps.scale = 1.0f;   // (its 1/4 is in the constant operands, TableScale::g1024)
     else ps.scale = seq ? 0.5f : 1.0f;         // radix-512 combine (unused by radix-256 passes)
   }
   if (fin != 1.0) {
     Pass& last = p->passes.back();
     const float f = static_cast<float>(fin);
-    if (last.kind == PassKind::Stockham || last.radix == 512) last.scale *= f;
+    if (last.kind == PassKind::Stockham || last.radix == 512 || last.radix == 1024) last.scale *= f;
     else if (p->tw4_modulus) last.tw_scale = f;
     else if (p->passes.size() >= 2) p->passes[p->passes.size() - 2].tw_scale = f;
     else if (once_log2 <= 8) ts.g *= fin;

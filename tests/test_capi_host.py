@@ -124,7 +124,7 @@ def test_planner_decompositions_multiply_to_n():
     for lg in range(1, 31):
         n = 1 << lg
         for inner in (1, 8, 16, 64, 4096):
-            for variant in (0, 32, 8388608, 16777216, 2097152, 16777216 | 8388608):
+            for variant in (0, 32, 8388608, 33554432, 8388608 | 33554432, 16777216, 2097152, 16777216 | 8388608):
                 d = tf.plan_describe(n, inner, variant)
                 toks = d.split()
                 rad = _radices(d)
@@ -146,17 +146,20 @@ def test_planner_decompositions_multiply_to_n():
 
 
 def test_planner_pass_counts():
-    """The pass counts DESIGN.md quotes: one pass up to 2^15, two up to 2^18, three up to 2^27 (contiguous axis)."""
+    """The pass counts DESIGN.md quotes: one pass up to 2^15, two up to 2^20, three up to 2^30 (contiguous axis)."""
     import tensor_fft_amd as tf
 
-    want = {8: 1, 9: 1, 10: 1, 11: 1, 12: 1, 13: 1, 14: 1, 15: 1, 16: 2, 17: 2, 18: 2, 19: 3, 20: 3, 21: 3, 22: 3, 23: 3,
-            24: 3, 25: 3, 26: 3, 27: 3, 28: 4, 29: 4}
+    want = {8: 1, 9: 1, 10: 1, 11: 1, 12: 1, 13: 1, 14: 1, 15: 1, 16: 2, 17: 2, 18: 2, 19: 2, 20: 2, 21: 3, 22: 3, 23: 3,
+            24: 3, 25: 3, 26: 3, 27: 3, 28: 3, 29: 3, 30: 3}
     for lg, passes in want.items():
         assert len(tf.plan_describe(1 << lg).split()) == passes, (lg, tf.plan_describe(1 << lg))
     assert tf.plan_describe(1 << 12) == "k4096:4096"
     assert tf.plan_describe(1 << 15) == "k4096r:8"
     assert tf.plan_describe(1 << 17) == "col:256+tw col:512"
-    assert tf.plan_describe(1 << 20) == "col:256+tw col:256+tw autosort:16-tw"
+    assert tf.plan_describe(1 << 19) == "col:512+tw col:1024"
+    assert tf.plan_describe(1 << 20) == "col:1024+tw col:1024"
+    assert tf.plan_describe(1 << 20, 1, 33554432) == "col:256+tw col:256+tw autosort:16-tw"
+    assert tf.plan_describe(1 << 28) == "col:512+tw col:512+tw col:1024"
     assert tf.plan_describe(1 << 26) == "col:256+tw col:512+tw col:512"
     assert tf.plan_describe(4096, 4096) == "col:256+tw autosort:16-tw"          # 2D column pass (general shapes)
     assert tf.plan_describe(512, 4096, 67108864) == "col:512"                    # second pass of the fused 4096^2 plan
@@ -171,7 +174,7 @@ def test_planner_pass_counts():
 # ---- select a timing-only kernel silently)
 DEBUG_VARIANTS = [4, 64, 128, 65536, 1 << 8, 3 << 8, 15 << 8, 4 | 8, 64 | 8, 524288 | 128]
 TUNER_VARIANTS = [0, 1, 2, 8, 9, 10, 16, 32, 4096, 8192, 131072, 262144, 524288, 1048576, 2097152, 4194304, 8388608,
-                  16777216, 16777216 | 8388608]
+                  16777216, 16777216 | 8388608, 33554432, 8388608 | 33554432]
 
 
 def test_variant_check_refuses_debug_and_unknown_bits(monkeypatch):

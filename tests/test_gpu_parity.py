@@ -382,16 +382,64 @@ def test_radix512_column_pass(tf, torch, orc, lg, batch):
     im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
     multi = 16777216 if lg <= 15 else 0          # 2^13..2^15 default to the single-pass kernel: ask for the column plan
     plan = tf.TfftPlan(n, batch, 0, variant=multi)
-    other = tf.TfftPlan(n, batch, 0, variant=multi | 8388608)
+    no512 = multi | 8388608 | 33554432           # (without the radix-1024 pass either, which would stand in at 2^18)
+    other = tf.TfftPlan(n, batch, 0, variant=no512)
     assert plan.num_launches == other.num_launches - 1
     gr, gi = _run(tf, torch, re, im, variant=multi)
     exact = _c(*orc.dft64(re, im))
     got = _c(gr, gi)
     assert np.isfinite(got).all()
     assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL
-    pr, pi = _run(tf, torch, re, im, variant=multi | 8388608)
+    pr, pi = _run(tf, torch, re, im, variant=no512)
     ref = _c(pr, pi)
     assert np.abs(got - exact).max() <= 1.5 * np.abs(ref - exact).max() + 2.0 ** -11 * np.abs(exact).max()
+
+
+@pytest.mark.parametrize("lg,batch", [(19, 1), (19, 3), (20, 1), (20, 5), (28, 1)])
+def test_radix1024_column_pass(tf, torch, orc, lg, batch):
+    """2^19 = 512 x 1024, 2^20 = 1024 x 1024 (two passes in natural order), 2^28 = 512 x 512 x 1024: the radix-1024 column
+    pass (four decimated radix-256 problems in two rounds, first-round results held in registers, radix-4 combine in two
+    read-outs; both output forms, with and without the next pass's twiddles) against the oracle's fp64 DFT / N (2^28: against
+    hipFFT complex64 on the device), and against the plan without it (variant bit 33554432), to fp16 rounding."""
+    n = 1 << lg
+    plan = tf.TfftPlan(n, batch, 0)
+    other = tf.TfftPlan(n, batch, 0, variant=33554432)
+    assert plan.num_launches == other.num_launches - 1
+    assert "col:1024" in tf.plan_describe(n, 1, 0) and "col:1024" not in tf.plan_describe(n, 1, 33554432)
+    if lg > 24:
+        gen = torch.Generator(device="cuda").manual_seed(lg)
+        x = (torch.rand(batch, 2, n, device="cuda", generator=gen) * 2 - 1).half()
+        flat = x.reshape(-1)
+        y = torch.empty_like(flat)
+        plan = tf.TfftPlan(n, batch, 0, preserve_input=True)
+        plan.exec(flat, flat[n:], y, y[n:])
+        want = torch.fft.fft(torch.complex(x[:, 0].float(), x[:, 1].float()), dim=1) / n
+        got = y.reshape(batch, 2, n)
+        got = torch.complex(got[:, 0].float(), got[:, 1].float())
+        rel = float(torch.linalg.vector_norm(got - want) / torch.linalg.vector_norm(want))
+        assert rel <= REL_L2_TOL, rel
+        assert float((got - want).abs().max()) <= 8 * 2.0 ** -11 * float(want.abs().max())
+        return
+    rng = np.random.default_rng(lg + batch)
+    re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
+    gr, gi = _run(tf, torch, re, im)
+    exact = _c(*orc.dft64(re, im))
+    got = _c(gr, gi)
+    assert np.isfinite(got).all()
+    assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL
+    pr, pi = _run(tf, torch, re, im, variant=33554432)
+    ref = _c(pr, pi)
+    assert np.abs(got - exact).max() <= 1.5 * np.abs(ref - exact).max() + 2.0 ** -11 * np.abs(exact).max()
+    # known answer: a tone at an arbitrary bin, amplitude chosen so that the line is 1.0
+    f0 = (5 * n) // 7
+    t = np.arange(n)
+    tone = np.exp(2j * np.pi * f0 * t / n)
+    tr, ti = _run(tf, torch, tone.real.astype(np.float16)[None], tone.imag.astype(np.float16)[None])
+    spec = _c(tr, ti)[0]
+    assert abs(spec[f0] - 1.0) <= 2e-3
+    spec[f0] = 0
+    assert np.abs(spec).max() <= 2e-3
 
 
 @pytest.mark.parametrize("lg", [13, 16, 17])
@@ -721,7 +769,7 @@ def test_one_plan_from_several_host_threads(tf, torch):
         assert bool((g_ == w_).all())
 
 
-@pytest.mark.parametrize("lg", [8, 9, 11, 12, 13, 15, 16, 17, 18, 20, 21, 23, 25, 26, 27])
+@pytest.mark.parametrize("lg", [8, 9, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21, 23, 25, 26, 27])
 def test_against_vendor_fft_on_device(tf, torch, lg):
     """Independent cross-check that needs no CPU oracle: hipFFT (through torch.fft, complex64) on the same fp16 input,
     the role cuFFT plays in the reference's tests (CuFFTTest.h:193-261). Large N run here in seconds."""

@@ -265,7 +265,7 @@ def test_debug_variants_are_refused_at_plan_creation(tf, monkeypatch):
     with pytest.raises(tf.TfftError):
         tf.TfftPlan(4096, 2, 0, variant=1 << 27)
     monkeypatch.setenv("TFFT_DEBUG_VARIANTS", "1")
-    assert tf.TfftPlan(1 << 20, 2, 0, variant=1 << 8).num_launches == 3      # tools/pass_breakdown.py still works
+    assert tf.TfftPlan(1 << 21, 2, 0, variant=1 << 8).num_launches == 3      # tools/pass_breakdown.py still works
 
 
 # ---------------------------------------------------------------------------------------------------------------
