@@ -67,8 +67,8 @@ struct Args {
   const float2* tw_hi;
   const uint8_t* tables;            // k4096::build_tables blob
   // tfft_plan_opts.scale (include/tfft.h): tw_scale multiplies the twiddles a TW pass applies (1, or the plan's single
-  // 1/N of "scale once" when this is the plan's last fp32 multiply); comb_scale is the factor of the radix-512 pass's
-  // fp32 radix-2 combine (1/2 for sequential scaling)
+  // 1/N of "scale once" when this is the plan's last fp32 multiply); comb_scale: read-out factor of a final radix-512 /
+  // radix-1024 pass under "scale once" (template parameter SC), otherwise unused
   float tw_scale;
   float comb_scale;
   // TW == kTwFourStep: output row k of flattened column m is multiplied by w_M^(k (tw4_col0 + m)), M = n_mask + 1 (the
@@ -688,9 +688,12 @@ constexpr int kWg512LdsBytes = kTab512 + 4 * WgGeom<4>::kPlane;       // 160 KiB
 #endif
 constexpr bool kLut512 = TFFT_LUT512;
 
-template <int MODE, int TW>
+// SC: multiply the output by Args::comb_scale in fp32 at the read-out (TFFT_SCALE_ONCE with this pass as the plan's last;
+// otherwise the combine's 1/2 is part of the constant operands and the combine is a plain sum).
+template <int MODE, int TW, bool SC = false>
 __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
   static_assert(TW != kTwFourStep || MODE == kColsInRegs, "the four-step twiddle exists for the columns-in-registers form");
+  static_assert(!SC || (MODE == kColsInRegs && TW == kTwNone), "the read-out factor exists for a final pass");
   using G = WgGeom<4>;
   constexpr int kHalf = G::kPlane;        // one sequence, one plane: 256 rows x 128 B
   constexpr int kPlaneAll = 2 * kHalf;    // RE -> IM distance
@@ -701,8 +704,8 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = wave >> 2, w4 = wave & 3;   // decimated sequence q, wave within its half
   for (int i = tid; i < kLdsTable / 16; i += kThreads) {
-    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(a.tables + kOffG)[i];
-    reinterpret_cast<u4*>(lds + kLdsTable)[i] = reinterpret_cast<const u4*>(a.tables + kOffG512)[i];
+    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(a.tables + kOffG512)[i];
+    reinterpret_cast<u4*>(lds + kLdsTable)[i] = reinterpret_cast<const u4*>(a.tables + kOffG512 + kLdsTable)[i];
   }
   const h8 f_re = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32);
   const h8 f_im = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32 + 16);
@@ -862,10 +865,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
         for (int e = 0; e < 8; ++e) {
           const float Ar = static_cast<float>(ar[e]), Br = static_cast<float>(br[e]);
           const float Ai = static_cast<float>(ai[e]), Bi = static_cast<float>(bi[e]);
-          x0r[e] = a.comb_scale * (Ar + Br);
-          x0i[e] = a.comb_scale * (Ai + Bi);
-          x1r[e] = a.comb_scale * (Ar - Br);
-          x1i[e] = a.comb_scale * (Ai - Bi);
+          x0r[e] = Ar + Br;
+          x0i[e] = Ai + Bi;
+          x1r[e] = Ar - Br;
+          x1i[e] = Ai - Bi;
         }
         if (TW) {
           const uint64_t av = (mb + f) >> a.a_shift;
@@ -927,15 +930,32 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       const u4 b_im = *reinterpret_cast<const u4*>(img + kPlaneAll + kHalf + 16 * L);
       const h8 ar = __builtin_bit_cast(h8, a_re), br = __builtin_bit_cast(h8, b_re);
       const h8 ai = __builtin_bit_cast(h8, a_im), bi = __builtin_bit_cast(h8, b_im);
+      const uint64_t o0 = obase + (static_cast<uint64_t>(k) << row_shift) + 8 * chunk;
+      const uint64_t o1 = o0 + (static_cast<uint64_t>(256) << row_shift);
+      if (TW == kTwNone && !SC) {
+        // last pass: X = A_0 +- A_1 is the output itself: packed binary16 sums (one correct rounding each, exactly what the
+        // fp32 path's sum-then-round gives, in 16 instructions instead of 80)
+        __builtin_nontemporal_store(__builtin_bit_cast(u4, ar + br), reinterpret_cast<u4*>(o_re + o0));
+        __builtin_nontemporal_store(__builtin_bit_cast(u4, ai + bi), reinterpret_cast<u4*>(o_im + o0));
+        __builtin_nontemporal_store(__builtin_bit_cast(u4, ar - br), reinterpret_cast<u4*>(o_re + o1));
+        __builtin_nontemporal_store(__builtin_bit_cast(u4, ai - bi), reinterpret_cast<u4*>(o_im + o1));
+        continue;
+      }
       float x0r[8], x0i[8], x1r[8], x1i[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float Ar = static_cast<float>(ar[e]), Br = static_cast<float>(br[e]);
         const float Ai = static_cast<float>(ai[e]), Bi = static_cast<float>(bi[e]);
-        x0r[e] = a.comb_scale * (Ar + Br);
-        x0i[e] = a.comb_scale * (Ai + Bi);
-        x1r[e] = a.comb_scale * (Ar - Br);
-        x1i[e] = a.comb_scale * (Ai - Bi);
+        x0r[e] = Ar + Br;
+        x0i[e] = Ai + Bi;
+        x1r[e] = Ar - Br;
+        x1i[e] = Ai - Bi;
+        if (SC) {
+          x0r[e] *= a.comb_scale;
+          x0i[e] *= a.comb_scale;
+          x1r[e] *= a.comb_scale;
+          x1i[e] *= a.comb_scale;
+        }
       }
       if (TW == kTwFourStep) {
         // rows k and k + 256 of column c_e = tw4_col0 + mb + 8 chunk + e: t0(e) = w_M^(k c_e), t1(e) = t0(e) w_M^(256 c_e);
@@ -960,28 +980,29 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
         }
       }
       if (TW == kTwNext) {
-        // E = av (kprev + ns k') mod T; kprev of column e of this chunk = (kprev_f0 + e) >> inner_shift
+        // E = av (kprev + ns k') mod T; kprev of column e of this chunk = (kprev_f0 + e) >> inner_shift. Both rows' twiddles
+        // run along e as recurrences (inner = 1, the only geometry this pass is planned for with a following pass: step
+        // w_T^av per column); inner > 1: the chunk's 8 columns share kprev.
         const uint64_t kprev_f0 = (mb + 8 * chunk) - (restb << a.ns_f_shift);
         const cpx row0 = lookup<kLut512>(a, (av * ((a.ns * k) & a.t_mask)) & a.t_mask);
-        const cpx row1 = cmul(row0, w_half);
         cpx col = lookup<kLut512>(a, (av * ((kprev_f0 >> a.inner_shift) & a.t_mask)) & a.t_mask);
         col.re *= a.tw_scale;
         col.im *= a.tw_scale;
+        cpx t0 = cmul(col, row0), t1 = cmul(t0, w_half);
+        const cpx stp = a.inner_shift == 0 ? w_av : cpx{1.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const cpx t0 = cmul(col, row0), t1 = cmul(col, row1);
           const float r0 = x0r[e] * t0.re - x0i[e] * t0.im, i0 = x0r[e] * t0.im + x0i[e] * t0.re;
           const float r1 = x1r[e] * t1.re - x1i[e] * t1.im, i1 = x1r[e] * t1.im + x1i[e] * t1.re;
           x0r[e] = r0; x0i[e] = i0; x1r[e] = r1; x1i[e] = i1;
-          if (a.inner_shift == 0) col = cmul(col, w_av);       // next column: kprev + 1 (inner > 1: 8 columns share kprev)
+          t0 = cmul(t0, stp);
+          t1 = cmul(t1, stp);
         }
       }
       const u4 s0r = {pk(x0r[0], x0r[1]), pk(x0r[2], x0r[3]), pk(x0r[4], x0r[5]), pk(x0r[6], x0r[7])};
       const u4 s0i = {pk(x0i[0], x0i[1]), pk(x0i[2], x0i[3]), pk(x0i[4], x0i[5]), pk(x0i[6], x0i[7])};
       const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
       const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
-      const uint64_t o0 = obase + (static_cast<uint64_t>(k) << row_shift) + 8 * chunk;
-      const uint64_t o1 = o0 + (static_cast<uint64_t>(256) << row_shift);
       __builtin_nontemporal_store(s0r, reinterpret_cast<u4*>(o_re + o0));
       __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(o_im + o0));
       __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(o_re + o1));

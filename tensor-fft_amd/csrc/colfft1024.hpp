@@ -351,9 +351,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
           __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(c_im + o0));
           __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(c_re + o0 + 512));
           __builtin_nontemporal_store(s1i, reinterpret_cast<u4*>(c_im + o0 + 512));
-#ifndef TFFT_C1024_NO_RO_SB
           __builtin_amdgcn_sched_barrier(0);     // one chunk at a time (registers)
-#endif
         }
         return;
       }
@@ -380,6 +378,18 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
         const h8 br = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + kHalf + 16 * L));
         const h8 ai = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + kPlaneAll + 16 * L));
         const h8 bi = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + kPlaneAll + kHalf + 16 * L));
+        const uint64_t o0 = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
+        const uint64_t o1 = o0 + (static_cast<uint64_t>(512) << a.ns_f_shift);
+        if (TW == kTwNone && !SC) {
+          // last pass: the combine IS the output: packed binary16 sums (one correct rounding each, what the fp32 path's
+          // sum-then-round gives, in 16 instructions instead of 80). -i D = (D.im, -D.re).
+          __builtin_nontemporal_store(__builtin_bit_cast(u4, j ? ar + bi : ar + br), reinterpret_cast<u4*>(o_re + o0));
+          __builtin_nontemporal_store(__builtin_bit_cast(u4, j ? ai - br : ai + bi), reinterpret_cast<u4*>(o_im + o0));
+          __builtin_nontemporal_store(__builtin_bit_cast(u4, j ? ar - bi : ar - br), reinterpret_cast<u4*>(o_re + o1));
+          __builtin_nontemporal_store(__builtin_bit_cast(u4, j ? ai + br : ai - bi), reinterpret_cast<u4*>(o_im + o1));
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
         float x0r[8], x0i[8], x1r[8], x1i[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -398,35 +408,33 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
           }
         }
         if (TW == kTwNext) {
-          // E = av (kprev + ns k_out) mod T; kprev of column e of this chunk = (kprev_f0 + e) >> inner_shift
+          // E = av (kprev + ns k_out) mod T; kprev of column e of this chunk = kprev_f0 + e (inner = 1 wherever this pass is
+          // planned): both rows' twiddles run along e as recurrences with step w_T^av
           const uint64_t kprev_f0 = (mb + 8 * chunk) - (restb << a.ns_f_shift);
           const cpx row0 = lookup<kLut512>(a, (av * ((a.ns * k) & a.t_mask)) & a.t_mask);
-          const cpx row1 = cmul(row0, w_half);
           cpx col = lookup<kLut512>(a, (av * ((kprev_f0 >> a.inner_shift) & a.t_mask)) & a.t_mask);
           col.re *= a.tw_scale;
           col.im *= a.tw_scale;
+          cpx t0 = cmul(col, row0), t1 = cmul(t0, w_half);
+          const cpx stp = a.inner_shift == 0 ? w_av : cpx{1.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const cpx t0 = cmul(col, row0), t1 = cmul(col, row1);
             const float r0 = x0r[e] * t0.re - x0i[e] * t0.im, i0 = x0r[e] * t0.im + x0i[e] * t0.re;
             const float r1 = x1r[e] * t1.re - x1i[e] * t1.im, i1 = x1r[e] * t1.im + x1i[e] * t1.re;
             x0r[e] = r0; x0i[e] = i0; x1r[e] = r1; x1i[e] = i1;
-            if (a.inner_shift == 0) col = cmul(col, w_av);       // next column: kprev + 1 (inner > 1: 8 columns share kprev)
+            t0 = cmul(t0, stp);
+            t1 = cmul(t1, stp);
           }
         }
         const u4 s0r = {pk(x0r[0], x0r[1]), pk(x0r[2], x0r[3]), pk(x0r[4], x0r[5]), pk(x0r[6], x0r[7])};
         const u4 s0i = {pk(x0i[0], x0i[1]), pk(x0i[2], x0i[3]), pk(x0i[4], x0i[5]), pk(x0i[6], x0i[7])};
         const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
         const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
-        const uint64_t o0 = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
-        const uint64_t o1 = o0 + (static_cast<uint64_t>(512) << a.ns_f_shift);
         __builtin_nontemporal_store(s0r, reinterpret_cast<u4*>(o_re + o0));
         __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(o_im + o0));
         __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(o_re + o1));
         __builtin_nontemporal_store(s1i, reinterpret_cast<u4*>(o_im + o1));
-#ifndef TFFT_C1024_NO_RO_SB
         __builtin_amdgcn_sched_barrier(0);
-#endif
       }
     };
 

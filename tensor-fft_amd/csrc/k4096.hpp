@@ -68,8 +68,8 @@ constexpr int kOffWR = kOffF1n + 2048;   // radix-R front end of k4096r.hpp as a
 // Column passes of radix 512 / 1024 (colfft.hpp, colfft1024.hpp): G with the combine twiddle of a decimated sequence folded
 // in, G_q[ka][n1][kb] = w_R^(q (ka + 16 kb)) G_ka[n1][kb]: one rounding of the constant instead of an fp32 multiply per output.
 constexpr int kOffG1024 = kOffWR + 3 * 512;     // R = 1024: q = 0 .. 3, 4 x 16 KiB (q = 0 differs from G by the scale only)
-constexpr int kOffG512 = kOffG1024 + 4 * 16384; // R = 512: q = 1, 16 KiB (q = 0 is G itself)
-constexpr int kTableBytes = kOffG512 + 16384;
+constexpr int kOffG512 = kOffG1024 + 4 * 16384; // R = 512: q = 0, 1, 2 x 16 KiB
+constexpr int kTableBytes = kOffG512 + 2 * 16384;
 
 // Contraction slot (lane group g, j) of stage 1 holds n2 = sigma(g, j): even rows
 // for lanes 0-31, odd rows for lanes 32-63, so that each 32-lane half of a
@@ -103,7 +103,9 @@ struct Addr {
 // MFMA stage; unscaled = 1; the k4096r front end leaves a factor 1/2 of headroom that tw gives back (tw = 2).
 struct TableScale {
   double f = 1.0 / 16, g = 1.0 / 16, h = 1.0 / 16, tw = 1.0;
-  double g1024 = 1.0 / 64;   // the radix-1024 pass's G_q: g times the factor of its radix-4 combine (1/4 sequential, 1 unscaled)
+  // G_q of the radix-1024 / radix-512 passes: g times the factor of their radix-4 / radix-2 combine (1/4, 1/2 sequential; 1
+  // unscaled), so that the combines are plain sums
+  double g1024 = 1.0 / 64, g512 = 1.0 / 32;
 };
 
 inline void build_tables(std::vector<uint8_t>& blob, const TableScale ts = TableScale()) {
@@ -187,9 +189,11 @@ inline void build_tables(std::vector<uint8_t>& blob, const TableScale ts = Table
           put_h(kOffG1024 + q * 16384 + k0 * 1024 + lane * 16 + 2 * j, c * ts.g1024);
           put_h(kOffG1024 + q * 16384 + k0 * 1024 + lane * 16 + 2 * (4 + j), -s * ts.g1024);
         }
-        cexp(static_cast<long>(2 * idx + 1) * (k0 + 16 * x), 512, c, s);
-        put_h(kOffG512 + k0 * 1024 + lane * 16 + 2 * j, c * ts.g);
-        put_h(kOffG512 + k0 * 1024 + lane * 16 + 2 * (4 + j), -s * ts.g);
+        for (int q = 0; q < 2; ++q) {                                 // (2 n1 + q)(k0 + 16 x) / 512
+          cexp(static_cast<long>(2 * idx + q) * (k0 + 16 * x), 512, c, s);
+          put_h(kOffG512 + q * 16384 + k0 * 1024 + lane * 16 + 2 * j, c * ts.g512);
+          put_h(kOffG512 + q * 16384 + k0 * 1024 + lane * 16 + 2 * (4 + j), -s * ts.g512);
+        }
       }
   }
 }

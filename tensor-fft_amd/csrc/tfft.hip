@@ -57,7 +57,7 @@ inline int ilog2(uint64_t x) {
 constexpr int kVarK4096 = 1 | 2 | 8 | 16;
 constexpr int kVarDebug = 4 | 64 | 128 | 65536 | (15 << 8);
 constexpr int kVarTuner = kVarK4096 | 32 | 4096 | 8192 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 |
-                          8388608 | 16777216 | 33554432 | 67108864;
+                          8388608 | 16777216 | 33554432 | 67108864 | 134217728;
 inline bool debug_variants_enabled() {
   const char* e = std::getenv("TFFT_DEBUG_VARIANTS");
   return e && e[0] == '1' && e[1] == 0;
@@ -178,15 +178,30 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
     if (col_ok) n256 = lg / 8;
     int rem = lg - 8 * n256;
     std::vector<int> radices(n256, 256);
-    // Radix-512 / radix-1024 column passes where they save a whole pass (2^15 = 512 x 64, 2^17 = 256 x 512, 2^18 = 512 x 512,
-    // 2^19 = 512 x 1024, 2^20 = 1024 x 1024, 2^23 = 256 x 512 x 64, 2^25, 2^26 = 256 x 512 x 512, 2^27 = 512^3, 2^28 =
-    // 512 x 512 x 1024 ...): the split lg = 8 a + 9 b + 10 c + t, t <= 7, with the fewest passes (a tail of t bits costs
-    // 0 / 1 / 2 passes for t = 0 / 1..6 / 7); ties go to the fewest radix-1024 passes, then the fewest radix-512 passes
-    // (their row segments are 128 bytes, not 256; the radix-1024 pass has eight workgroup barriers per tile).
-    // variant bit 8388608 turns the radix-512 passes off, 33554432 the radix-1024 passes.
+    // Radix-512 / radix-1024 column passes where they save a whole pass (2^15 = 512 x 64, 2^17 = 512 x 256, 2^19 = 1024 x 512,
+    // 2^20 = 1024 x 1024, 2^26 = 1024 x 256 x 256, 2^28 .. 2^30 in three passes). Contiguous axis, 2^16 .. 2^30, default
+    // variant: the split measured fastest among all orders of all splits with the fewest passes (tools/plan_scan.py,
+    // profiles/r2_plan_scan.txt). The wide radices go FIRST: a radix-1024 first pass writes 2-KiB runs per column, and a
+    // radix-256 last pass keeps its 256-byte row segments.
+    static const int kColSplit[15][3] = {
+        {1024, 0, 0},     {512, 256, 0},    {1024, 256, 0},    {1024, 512, 0},     {1024, 1024, 0},      // 2^16 .. 2^20
+        {256, 256, 0},    {256, 256, 0},    {512, 256, 0},     {1024, 256, 0},     {1024, 1024, 0},      // 2^21 .. 2^25
+        {1024, 256, 256}, {1024, 512, 256}, {256, 1024, 1024}, {1024, 512, 1024},  {1024, 1024, 1024}};  // 2^26 .. 2^30
     const bool use512 = col_ok && inner == 1 && lg >= 15 && !(variant & 8388608);
     const bool use1024 = col_ok && inner == 1 && lg >= 16 && !(variant & 33554432);
-    if (use512 || use1024) {
+    if (use512 && use1024 && lg >= 16 && lg <= 30 && !(variant & 134217728)) {
+      radices.clear();
+      int bits = 0;
+      for (int i = 0; i < 3 && kColSplit[lg - 16][i]; ++i) {
+        radices.push_back(kColSplit[lg - 16][i]);
+        bits += ilog2(static_cast<uint64_t>(kColSplit[lg - 16][i]));
+      }
+      n256 = static_cast<int>(radices.size());
+      rem = lg - bits;
+    } else if (use512 || use1024) {
+      // restricted variants (no radix-512: 8388608, no radix-1024: 33554432) and 2^15: the split lg = 8 a + 9 b + 10 c + t,
+      // t <= 7, with the fewest passes (a tail of t bits costs 0 / 1 / 2 passes for t = 0 / 1..6 / 7); ties go to the
+      // fewest radix-1024, then the fewest radix-512 passes, or with variant bit 134217728 to the most; wide radices first.
       auto tail_cost = [](int t) { return t == 0 ? 0 : (t <= 6 ? 1 : 2); };
       int best_a = n256, best_b = 0, best_c = 0, best_cost = n256 + tail_cost(rem);
       for (int c = 0; c <= (use1024 ? 3 : 0); ++c)
@@ -196,7 +211,9 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
             const int t = lg - 8 * a2 - 9 * b - 10 * c;
             if (t > 7) continue;
             const int cost = a2 + b + c + tail_cost(t);
-            if (cost < best_cost) {
+            const bool wide = (variant & 134217728) && cost == best_cost &&
+                              (c > best_c || (c == best_c && b > best_b));
+            if (cost < best_cost || wide) {
               best_cost = cost;
               best_a = a2;
               best_b = b;
@@ -204,9 +221,9 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
             }
           }
       n256 = best_a + best_b + best_c;      // column passes in total
-      radices.assign(best_a, 256);
+      radices.assign(best_c, 1024);
       radices.insert(radices.end(), best_b, 512);
-      radices.insert(radices.end(), best_c, 1024);
+      radices.insert(radices.end(), best_a, 256);
       rem = lg - 8 * best_a - 9 * best_b - 10 * best_c;
     }
     // n = 512 along a strided axis as ONE radix-512 column pass (variant bit 67108864; the second pass of the fused 2D plan)
@@ -214,6 +231,28 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
       radices.assign(1, 512);
       n256 = 1;
       rem = 0;
+    }
+    // experiment knob (honoured only with TFFT_DEBUG_VARIANTS=1): TFFT_PLAN_COLS="512,512,256" replaces the column passes of a
+    // contiguous-axis plan by the given radices in the given order (their product must divide n; the tail follows as usual)
+    if (col_ok && inner == 1 && lg >= 16 && debug_variants_enabled()) {
+      if (const char* e = std::getenv("TFFT_PLAN_COLS")) {
+        std::vector<int> cols;
+        int bits = 0;
+        for (const char* q = e; *q;) {
+          const int r = std::atoi(q);
+          if (r == 256 || r == 512 || r == 1024) {
+            cols.push_back(r);
+            bits += ilog2(static_cast<uint64_t>(r));
+          }
+          while (*q && *q != ',') ++q;
+          if (*q == ',') ++q;
+        }
+        if (!cols.empty() && bits <= lg && (n >> bits) * 1 >= 1 && lg - bits <= 7) {
+          radices = cols;
+          n256 = static_cast<int>(cols.size());
+          rem = lg - bits;
+        }
+      }
     }
     for (; rem >= 4; rem -= 4) radices.push_back(16);
     if (rem) radices.push_back(1 << rem);
@@ -493,6 +532,8 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwFourStep>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
       else if (ps.tw_next)
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+      else if (ps.scale != 1.0f)         // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out
+        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
       else
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
     }
@@ -809,7 +850,7 @@ int tfft_max_no_optin_shared_mem(int device_id) {
 namespace {
 
 // tfft_plan_opts.scale -> constant operands and per-pass factors (include/tfft.h, TFFT_SCALE_*). Sequential: 1/16 per
-// MFMA stage in F / G / H, 1/R per autosort pass, 1/2 in the radix-512 combine, 1/4 in the radix-1024 pass's G_q. None: all
+// MFMA stage in F / G / H, 1/R per autosort pass, 1/2 and 1/4 in the G_q of the radix-512 / radix-1024 passes. None: all
 // of them 1. Once: as none, and
 // the single factor 2^-once_log2 rides on the LAST fp32 multiply of the plan: the inter-stage twiddle block of a
 // single-kernel plan, the butterfly output of a final autosort pass, the combine of a final radix-512 / radix-1024 pass, the
@@ -820,7 +861,7 @@ int apply_scale_mode(tfft_plan* p, const InternalOpts& io, k4096::TableScale& ts
   const double s16 = seq ? 1.0 / 16 : 1.0;
   const int once_log2 = io.once_log2 >= 0 ? io.once_log2 : ilog2(p->n);
   const double fin = p->scale_mode == TFFT_SCALE_ONCE ? std::ldexp(1.0, -once_log2) : 1.0;
-  ts = k4096::TableScale{s16, s16, s16, 1.0, seq ? s16 / 4 : s16};
+  ts = k4096::TableScale{s16, s16, s16, 1.0, seq ? s16 / 4 : s16, seq ? s16 / 2 : s16};
   r_fa = r_fb = s16;
   r_s = 1.0;
   if (io.rows2d) ts.tw = 2.0;                  // fused 2D row pass: the front end's headroom factor (k4096r.hpp)
@@ -834,8 +875,8 @@ int apply_scale_mode(tfft_plan* p, const InternalOpts& io, k4096::TableScale& ts
   for (Pass& ps : p->passes) {
     ps.tw_scale = 1.0f;
     if (ps.kind == PassKind::Stockham) ps.scale = seq ? 1.0f / ps.radix : 1.0f;
-    else if (ps.radix == 1024) ps.scale = 1.0f;   // (its 1/4 is in the constant operands, TableScale::g1024)
-    else ps.scale = seq ? 0.5f : 1.0f;         // radix-512 combine (unused by radix-256 passes)
+    else ps.scale = 1.0f;                      // column passes: the radix-512 / radix-1024 combines have their 1/2, 1/4 in the
+                                               // constant operands (TableScale::g512, g1024); read-out factor of "scale once" only
   }
   if (fin != 1.0) {
     Pass& last = p->passes.back();

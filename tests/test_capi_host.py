@@ -124,7 +124,7 @@ def test_planner_decompositions_multiply_to_n():
     for lg in range(1, 31):
         n = 1 << lg
         for inner in (1, 8, 16, 64, 4096):
-            for variant in (0, 32, 8388608, 33554432, 8388608 | 33554432, 16777216, 2097152, 16777216 | 8388608):
+            for variant in (0, 32, 8388608, 33554432, 8388608 | 33554432, 134217728, 16777216, 2097152, 16777216 | 8388608):
                 d = tf.plan_describe(n, inner, variant)
                 toks = d.split()
                 rad = _radices(d)
@@ -155,12 +155,15 @@ def test_planner_pass_counts():
         assert len(tf.plan_describe(1 << lg).split()) == passes, (lg, tf.plan_describe(1 << lg))
     assert tf.plan_describe(1 << 12) == "k4096:4096"
     assert tf.plan_describe(1 << 15) == "k4096r:8"
-    assert tf.plan_describe(1 << 17) == "col:256+tw col:512"
-    assert tf.plan_describe(1 << 19) == "col:512+tw col:1024"
+    assert tf.plan_describe(1 << 17) == "col:512+tw col:256"
+    assert tf.plan_describe(1 << 16) == "col:1024+tw autosort:64-tw"
+    assert tf.plan_describe(1 << 19) == "col:1024+tw col:512"
     assert tf.plan_describe(1 << 20) == "col:1024+tw col:1024"
     assert tf.plan_describe(1 << 20, 1, 33554432) == "col:256+tw col:256+tw autosort:16-tw"
-    assert tf.plan_describe(1 << 28) == "col:512+tw col:512+tw col:1024"
-    assert tf.plan_describe(1 << 26) == "col:256+tw col:512+tw col:512"
+    assert tf.plan_describe(1 << 28) == "col:256+tw col:1024+tw col:1024"
+    assert tf.plan_describe(1 << 28, 1, 134217728) == "col:1024+tw col:1024+tw col:256"
+    assert tf.plan_describe(1 << 27, 1, 33554432) == "col:512+tw col:512+tw col:512"
+    assert tf.plan_describe(1 << 26) == "col:1024+tw col:256+tw col:256"
     assert tf.plan_describe(4096, 4096) == "col:256+tw autosort:16-tw"          # 2D column pass (general shapes)
     assert tf.plan_describe(512, 4096, 67108864) == "col:512"                    # second pass of the fused 4096^2 plan
     assert tf.plan_describe(1 << 13, 1, 16777216) == "col:256+tw autosort:32-tw"
@@ -174,7 +177,7 @@ def test_planner_pass_counts():
 # ---- select a timing-only kernel silently)
 DEBUG_VARIANTS = [4, 64, 128, 65536, 1 << 8, 3 << 8, 15 << 8, 4 | 8, 64 | 8, 524288 | 128]
 TUNER_VARIANTS = [0, 1, 2, 8, 9, 10, 16, 32, 4096, 8192, 131072, 262144, 524288, 1048576, 2097152, 4194304, 8388608,
-                  16777216, 16777216 | 8388608, 33554432, 8388608 | 33554432]
+                  16777216, 16777216 | 8388608, 33554432, 8388608 | 33554432, 134217728]
 
 
 def test_variant_check_refuses_debug_and_unknown_bits(monkeypatch):
@@ -188,7 +191,7 @@ def test_variant_check_refuses_debug_and_unknown_bits(monkeypatch):
             assert e.value.code == 5 and "TFFT_DEBUG_VARIANTS" in e.value.message
             with pytest.raises(tf.TfftError):
                 tf.plan_describe(n, 1, v)
-        for v in (1 << 27, 1 << 30, -1, 1 << 12 | 1 << 28):
+        for v in (1 << 29, 1 << 30, -1, 1 << 12 | 1 << 28):
             with pytest.raises(tf.TfftError) as e:
                 capi.variant_check(n, 1, v)
             assert "unknown" in e.value.message
@@ -204,7 +207,7 @@ def test_tuner_file_with_unusable_variant_is_refused(tmp_path, capsys, monkeypat
     monkeypatch.delenv("TFFT_DEBUG_VARIANTS", raising=False)
     f = tmp_path / "TunerResults.dat"
     f.write_text("4096 4096 16 1 256 64\n65536 4096 16 1 256 65536\n1048576 4096 16 1 256 524288\n"
-                 "262144 4096 16 1 256 notanumber\n131072 4096 16 1 256 134217728\n")
+                 "262144 4096 16 1 256 notanumber\n131072 4096 16 1 256 536870912\n")
     assert tf.CreatePlan(4096, str(f)) is None                      # 64 = no-compute timing kernel
     assert tf.CreatePlan(65536, str(f)) is None                     # 65536 = copy-only column pass
     assert tf.CreatePlan(262144, str(f)) is None

@@ -263,7 +263,7 @@ def test_debug_variants_are_refused_at_plan_creation(tf, monkeypatch):
             tf.TfftPlan(n, 2, 0, variant=v)
         assert "TFFT_DEBUG_VARIANTS" in e.value.message
     with pytest.raises(tf.TfftError):
-        tf.TfftPlan(4096, 2, 0, variant=1 << 27)
+        tf.TfftPlan(4096, 2, 0, variant=1 << 29)
     monkeypatch.setenv("TFFT_DEBUG_VARIANTS", "1")
     assert tf.TfftPlan(1 << 21, 2, 0, variant=1 << 8).num_launches == 3      # tools/pass_breakdown.py still works
 
