@@ -107,7 +107,9 @@ typedef struct tfft_plan_opts {
                            these (default = 2|8; 1 and 2 exclude each other).
                            Any N: 32 = plain autosort chain (no column kernel); 2097152 = do not fuse the
                            radix-16 + radix-2/4 tail into one radix-32/64 pass; 8388608 = no radix-512 column
-                           passes; 16777216 = N = 8192..32768 as a column plan instead of the single-pass kernel; 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
+                           passes; 33554432 = no radix-1024 column passes; 134217728 = among the splits with the
+                           fewest passes, the one with the most radix-1024 (then radix-512) passes instead of the
+                           measured default; 16777216 = N = 8192..32768 as a column plan instead of the single-pass kernel; 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
                            Column passes: 131072 = per-wave kernel, 524288 = 4-wave cooperative workgroups,
                            262144 = no non-temporal accesses, 1048576 = 16-byte stores straight from registers,
                            4096 / 8192 = per-wave kernel with LDS-staged stores / hardware sin-cos twiddles.
