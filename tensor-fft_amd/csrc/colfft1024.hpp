@@ -146,13 +146,15 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
       *reinterpret_cast<u4*>(img_q + kPlaneAll + 8192 * w4 + 1024 * i + 16 * ll) = ra_im[i];
     }
   };
-  if (blockIdx.x < total) issue_loads(blockIdx.x);
+  // (an XCD-aware order, 32 adjacent blocks per XCD at a time, was measured: +0.9 % at 2^20, -0.3 % at 2^25; not kept)
+  const uint32_t bid0 = blockIdx.x;
+  if (bid0 < total) issue_loads(bid0);
 
   // B_q of the first round, then E_1 / D_1. Columns in registers: [ka >> 1][2 (ka & 1) + {0, 1}] = columns {0,1}, {2,3} of
   // tile ka; columns on lanes: [ka >> 1][r] = rows (ka - 1, ka) of register r.
   uint32_t sv_re[8][4], sv_im[8][4];
 
-  for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+  for (uint32_t blk = bid0; blk < total; blk += gridDim.x) {
     const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;
     const uint64_t bidx = gc0 >> pshift;                     // pitch >= 64: one batch entry per block
     const uint64_t mb = gc0 & (a.pitch - 1);
