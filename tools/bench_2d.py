@@ -6,6 +6,9 @@ import torch
 import __graft_entry__ as g
 g.build()
 import tensor_fft_amd as tf
+if os.environ.get("TFFT_AB_LIB"):            # A/B of another build of the library (file name under tensor-fft_amd/)
+    from tensor_fft_amd import capi
+    capi._LIB_NAME = os.environ["TFFT_AB_LIB"]
 n = 4096
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 re = ((torch.rand(b * n * n, device="cuda") * 2 - 1)).half(); im = ((torch.rand(b * n * n, device="cuda") * 2 - 1)).half()
@@ -21,4 +24,4 @@ e0.record()
 for _ in range(5): plan.exec(re, im, o_re, o_im)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-print(f"2D {n}x{n} batch {b}: {ms:.2f} ms, launches {plan.num_launches}, {b*n*n/ms/1e6:.1f} Gsamples/s, {16*b*n*n/ms/1e6:.0f} GB/s vs 2-pass minimum")
+print(f"{os.environ.get('TFFT_AB_LIB', 'libtfft.so')}: 2D {n}x{n} batch {b}: {ms:.2f} ms, launches {plan.num_launches}, {b*n*n/ms/1e6:.1f} Gsamples/s, {16*b*n*n/ms/1e6:.0f} GB/s vs 2-pass minimum")
