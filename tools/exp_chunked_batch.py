@@ -1,6 +1,6 @@
 """Does running a long-transform batch in cache-sized sub-batches (all passes of one sub-batch back to back) beat one
 plan over the whole batch? The 256-MiB Infinity Cache could keep a sub-batch's intermediate between passes.
-usage: python tools/exp_chunked_batch.py N batch chunk [chunk ...]"""
+usage: [TFFT_VARIANT=262144] python tools/exp_chunked_batch.py N batch chunk [chunk ...]   (262144 = no non-temporal accesses)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,6 +8,10 @@ import torch
 import __graft_entry__ as g
 g.build()
 import tensor_fft_amd as tf
+if os.environ.get("TFFT_AB_LIB"):            # another build of the library (file name under tensor-fft_amd/)
+    from tensor_fft_amd import capi
+    capi._LIB_NAME = os.environ["TFFT_AB_LIB"]
+    capi._lib = None                            # (g.build() above has already loaded the default build)
 n, batch = int(sys.argv[1]), int(sys.argv[2])
 chunks = [int(v) for v in sys.argv[3:]]
 x = ((torch.rand(batch * 2 * n, device="cuda") * 2 - 1)).half(); y = torch.empty_like(x)
@@ -19,7 +23,7 @@ def timed(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 for c in [batch] + chunks:
-    plan = tf.TfftPlan(n, c, 0, preserve_input=True)
+    plan = tf.TfftPlan(n, c, 0, preserve_input=True, variant=int(os.environ.get("TFFT_VARIANT", "0")))
     ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
     if plan.workspace_bytes: plan.set_workspace(ws)
     def run():
