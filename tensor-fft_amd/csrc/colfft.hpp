@@ -133,7 +133,8 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
   // copy-in geometry: instruction i, lane l: h = l & 1, i_hi = (l >> 1) & 15, i_lo = 2 i + (l >> 5)
   const uint64_t in_lane_off = (static_cast<uint64_t>(16 * ((lane >> 1) & 15) + (lane >> 5)) * a.pitch + 8 * (lane & 1)) * 2;
 
-  for (uint32_t task = blockIdx.x * kWavesPerBlock + wave; task < a.tasks; task += gridDim.x * kWavesPerBlock) {
+  Rotor rot(blockIdx.x, gridDim.x);                                      // (workgroup order: k4096::Rotor)
+  for (uint32_t task = rot.item() * kWavesPerBlock + wave; task < a.tasks; rot.advance(), task = rot.item() * kWavesPerBlock + wave) {
     const uint32_t bidx = task / a.groups;
     const uint64_t m0 = static_cast<uint64_t>(task - bidx * a.groups) * 16;
     const uint8_t* src_re = reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride + m0) + in_lane_off;
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
 
   // (adjacent column blocks run on different CUs at the same time: measured 1-2 % faster than giving each
   // workgroup a contiguous range of blocks)
-  for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+  Rotor rot(blockIdx.x, gridDim.x);                                      // (block order: k4096::Rotor)
+  for (uint32_t blk = rot.item(); blk < total; rot.advance(), blk = rot.item()) {
     const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;        // first flattened column of the block
     const uint64_t gcw = gc0 + 16 * wave;                              // ... of this wave
     const uint64_t bidx = gcw >> pshift;                               // this wave's batch entry
@@ -745,9 +747,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       raw_im[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off));
     }
   };
-  if (blockIdx.x < total) issue_loads(blockIdx.x);
+  Rotor rot(blockIdx.x, gridDim.x);                          // (block order: k4096::Rotor)
+  if (rot.item() < total) issue_loads(rot.item());
 
-  for (uint32_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+  for (uint32_t blk = rot.item(); blk < total; rot.advance(), blk = rot.item()) {
     const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;
     const uint64_t bidx = gc0 >> pshift;                     // pitch >= 64: one batch entry per block
     const uint64_t mb = gc0 & (a.pitch - 1);
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // C: A_0 and A_1 are complete
-    if (blk + gridDim.x < total) issue_loads(blk + gridDim.x);     // the next block's input starts flying now
+    if (rot.peek() < total) issue_loads(rot.peek());               // the next block's input starts flying now
 
     if (MODE == kColsOnLanes) {
       // ---- radix-2 combine at read-out: 16-byte chunks = 8 consecutive k of one column; a column's 512 outputs are

@@ -146,15 +146,17 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
       *reinterpret_cast<u4*>(img_q + kPlaneAll + 8192 * w4 + 1024 * i + 16 * ll) = ra_im[i];
     }
   };
-  // (an XCD-aware order, 32 adjacent blocks per XCD at a time, was measured: +0.9 % at 2^20, -0.3 % at 2^25; not kept)
-  const uint32_t bid0 = blockIdx.x;
+  // (block order: k4096::Rotor. An XCD-aware order, 32 adjacent blocks per XCD at a time, changed nothing: +0.9 % at 2^20,
+  // -0.3 % at 2^25)
+  Rotor rot(blockIdx.x, gridDim.x);
+  const uint32_t bid0 = rot.item();
   if (bid0 < total) issue_loads(bid0);
 
   // B_q of the first round, then E_1 / D_1. Columns in registers: [ka >> 1][2 (ka & 1) + {0, 1}] = columns {0,1}, {2,3} of
   // tile ka; columns on lanes: [ka >> 1][r] = rows (ka - 1, ka) of register r.
   uint32_t sv_re[8][4], sv_im[8][4];
 
-  for (uint32_t blk = bid0; blk < total; blk += gridDim.x) {
+  for (uint32_t blk = bid0; blk < total; rot.advance(), blk = rot.item()) {
     const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;
     const uint64_t bidx = gc0 >> pshift;                     // pitch >= 64: one batch entry per block
     const uint64_t mb = gc0 & (a.pitch - 1);
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
                                              // landed when they have)
     // the next block's first round starts flying now. Unconditional (the last iteration re-reads its own block): a
     // conditional load keeps the OLD register contents alive through the whole loop body as far as the compiler can tell.
-    issue_loads(blk + gridDim.x < total ? blk + gridDim.x : blk);
+    issue_loads(rot.peek() < total ? rot.peek() : blk);
 
     // ---- read-out j: rows k + 256 j and k + 256 j + 512 from the pair (E_j, O_j / D_j) in the image
     //   j = 0:  X = E_0 +- O_0        j = 1:  X = E_1 -+ i D_1   (-i D = (D.im, -D.re))

@@ -232,6 +232,23 @@ __device__ __forceinline__ f4 mfma(h8 a, h8 b) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, z, 0, 0, 0);
 }
 
+// Work distribution of the persistent (grid-stride) kernels: in round t workgroup g takes item t G + (g + t) mod G instead
+// of t G + g. With the plain stride a workgroup only ever sees items of ONE residue class modulo 8 (G = 256 CUs): for a column
+// pass that is one value of the address bits 7..9 of its 128-byte row segments, and the segments with bits 7..9 = 011 are
+// served ~23 % more slowly by this memory system than the other seven classes (measured per workgroup with wall_clock64:
+// the 32 workgroups of that class finish at 1.91 ms, all others at 1.53 ms; with the rotation everything ends at 1.50-1.53
+// ms: 2^20 x 1024 295 -> 346 Gsamples/s). Rotating makes every workgroup take all eight classes in turn.
+struct Rotor {
+  uint32_t g, n, pos, rnd;
+  __device__ Rotor(uint32_t block, uint32_t grid) : g(block), n(grid), pos(block), rnd(0) {}
+  __device__ uint32_t item() const { return rnd * n + pos; }
+  __device__ uint32_t peek() const { return (rnd + 1) * n + (pos + 1 == n ? 0 : pos + 1); }      // next round's item
+  __device__ void advance() {
+    ++rnd;
+    pos = (pos + 1 == n) ? 0 : pos + 1;
+  }
+};
+
 // Kernel variants (tuner knob, see tfft_plan_opts::variant):
 //   kPrefetch   issue the next transform's HBM->LDS copy as soon as stage 1 has read the
 //               current one out of LDS, so it flies under stages 2/3 and the stores.

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       for (int j = 0; j < 4; ++j) raw[j][jj] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src + 128 * j));
     }
   };
-  if (blockIdx.x < groups_total) issue_loads(blockIdx.x);
+  Rotor rot(blockIdx.x, gridDim.x);                       // (iteration order: k4096::Rotor)
+  if (rot.item() < groups_total) issue_loads(rot.item());
 
   // output side of the front-end product: lane (g, n) holds rows rho' = 4 g + r: outputs s2a (r = 0, 1: re, im) and
   // s2a + 1 (r = 2, 3) of column set h'
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   const float sb_re = __builtin_amdgcn_cosf(static_cast<float>(s2a + 1) * (1.0f / kN)),
               sb_im = -__builtin_amdgcn_sinf(static_cast<float>(s2a + 1) * (1.0f / kN));
 
-  for (uint32_t it = blockIdx.x; it < groups_total; it += gridDim.x) {
+  for (uint32_t it = rot.item(); it < groups_total; rot.advance(), it = rot.item()) {
     // a group past the end of the batch re-does the last transform (it keeps the barriers uniform) without storing
     const uint32_t b_raw = ROWS ? (it >> 9) : it * kGroups + grp;      // ROWS: image index; r0 = it & 511
     const bool live = ROWS || b_raw < batch;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // B: u_0 .. u_(R-1) are complete
     // the raw registers are free: the next iteration's input starts flying now
-    if (it + gridDim.x < groups_total) issue_loads(it + gridDim.x);
+    if (rot.peek() < groups_total) issue_loads(rot.peek());
 
     // ---- stage 1 on this wave's own region, exactly the 4096 kernel's: D1_n1[k0 = 4g + r][n0 = lane & 15]
     uint32_t pr[8][4], pi[8][4];
