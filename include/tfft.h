@@ -109,10 +109,7 @@ typedef struct tfft_plan_opts {
                            radix-16 + radix-2/4 tail into one radix-32/64 pass; 8388608 = no radix-512 column
                            passes; 33554432 = no radix-1024 column passes; 134217728 = among the splits with the
                            fewest passes, the one with the most radix-1024 (then radix-512) passes instead of the
-                           measured default; 268435456 = keep a multi-pass plan on the caller's stream (by default a
-                           multi-pass plan over >= 2^26 samples runs as two half-batches, the second on a stream of
-                           the plan's own, forked from and joined to the caller's stream by events; the environment
-                           variable TFFT_NO_SPLIT=1 does the same for every plan of the process); 16777216 = N = 8192..32768 as a column plan instead of the single-pass kernel; 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
+                           measured default; 16777216 = N = 8192..32768 as a column plan instead of the single-pass kernel; 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
                            Column passes: 131072 = per-wave kernel, 524288 = 4-wave cooperative workgroups,
                            262144 = no non-temporal accesses, 1048576 = 16-byte stores straight from registers,
                            4096 / 8192 = per-wave kernel with LDS-staged stores / hardware sin-cos twiddles.

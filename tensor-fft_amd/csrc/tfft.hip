@@ -57,7 +57,7 @@ inline int ilog2(uint64_t x) {
 constexpr int kVarK4096 = 1 | 2 | 8 | 16;
 constexpr int kVarDebug = 4 | 64 | 128 | 65536 | (15 << 8);
 constexpr int kVarTuner = kVarK4096 | 32 | 4096 | 8192 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 |
-                          8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456;
+                          8388608 | 16777216 | 33554432 | 67108864 | 134217728;
 inline bool debug_variants_enabled() {
   const char* e = std::getenv("TFFT_DEBUG_VARIANTS");
   return e && e[0] == '1' && e[1] == 0;
@@ -111,7 +111,6 @@ struct InternalOpts {
   uint64_t in_gstride = 0, out_gstride = 0;
   int once_log2 = -1;                    // TFFT_SCALE_ONCE: exponent of the single factor (default log2 n)
   bool rows2d = false;                   // tables for the fused 2D row pass (k4096r front end in front of the 4096 kernel)
-  bool no_split = false;                 // this plan IS one half of a split plan
 };
 
 }  // namespace
@@ -136,14 +135,6 @@ struct tfft_plan {
   // contiguous N2-point transforms out of it; this plan then only owns the two sub-plans and the workspace
   tfft_plan* sub_col = nullptr;
   tfft_plan* sub_row = nullptr;
-  // Multi-pass plans over a large batch run as TWO half-batches, the second on a stream of the plan's own (forked from and
-  // joined to the caller's stream with events): while one half's pass n + 1 and the other's pass n are both in flight, a
-  // CU that has finished its share of one kernel goes on with the other instead of idling to the end of the launch
-  // (measured +3 .. +8 %, tools/exp_streams_chunked.py). half[0] / half[1] are complete plans for the two halves.
-  tfft_plan* half[2] = {nullptr, nullptr};
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  mutable std::mutex split_mutex;   // one enqueue of the fork / two chains / join at a time
   void* d_tables = nullptr;     // k4096::build_tables blob (K4096 and Col256 passes)
   float2* d_tw_lo = nullptr;    // w_n tables (Col256 and Stockham passes)
   float2* d_tw_hi = nullptr;
@@ -664,35 +655,6 @@ int ensure_workspace(const tfft_plan* p) {
 
 int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                  hipStream_t s) {
-  if (p->half[0]) {
-    // fork: the side stream starts behind everything already enqueued on s; join: s continues behind both halves. (Under
-    // stream capture the side stream joins the capture through the event, the usual fork / join pattern.)
-    std::lock_guard<std::mutex> lock(p->split_mutex);
-    const uint64_t b0 = p->half[0]->batch;
-    const size_t w0 = tfft_plan_workspace_bytes(p->half[0]), w1 = tfft_plan_workspace_bytes(p->half[1]);
-    if (w0 + w1) {
-      const int rc = ensure_workspace(p);
-      if (rc) return rc;
-      p->half[0]->ws = p->ws;
-      p->half[0]->ws_bytes = w0;
-      p->half[1]->ws = static_cast<uint8_t*>(p->ws) + w0;
-      p->half[1]->ws_bytes = w1;
-    }
-    const _Float16* const i_re = static_cast<const _Float16*>(in_re);
-    const _Float16* const i_im = static_cast<const _Float16*>(in_im);
-    _Float16* const o_re = static_cast<_Float16*>(out_re);
-    _Float16* const o_im = static_cast<_Float16*>(out_im);
-    TFFT_HIP(hipEventRecord(p->ev_fork, s));
-    TFFT_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-    int rc = launch_chain(p->half[1], i_re + b0 * p->in_stride, i_im + b0 * p->in_stride, o_re + b0 * p->out_stride,
-                          o_im + b0 * p->out_stride, p->side);
-    if (rc) return rc;
-    rc = launch_chain(p->half[0], in_re, in_im, out_re, out_im, s);
-    if (rc) return rc;
-    TFFT_HIP(hipEventRecord(p->ev_join, p->side));
-    TFFT_HIP(hipStreamWaitEvent(s, p->ev_join, 0));
-    return TFFT_OK;
-  }
   if (p->sub_col) {
     // TFFT_ORDER_TRANSPOSED: column pass in -> planar workspace, row pass workspace -> out (in place is fine: the input
     // has been read completely before the row pass writes)
@@ -1020,38 +982,7 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
     g_err = keep;
     return code;
   };
-  // ---- two half-batches on two streams (see tfft_plan::half): multi-pass plans of N >= 2^17 along a contiguous axis over at
-  // least 2^27 samples (below either bound the second set of launches costs what the overlap gains: 2^16 -2 %, 2^26 samples -1 %); variant bit 268435456 or TFFT_NO_SPLIT=1 in
-  // the environment keep everything on the caller's stream
-  auto split_allowed = [&]() {
-    static const bool no_split_env = [] { const char* e = std::getenv("TFFT_NO_SPLIT"); return e && e[0] == '1'; }();
-    const bool partial = (pvariant >> 8) & 15;
-    return !io.no_split && !no_split_env && !(pvariant & 268435456) && !partial && batch >= 2 && n >= (uint64_t{1} << 17) &&
-           batch * n >= (uint64_t{1} << 27);
-  };
-  auto make_split = [&]() -> int {
-    tfft_plan_opts ho = opts ? *opts : tfft_plan_opts{};
-    ho.in_batch_stride = in_stride;
-    ho.out_batch_stride = out_stride;
-    InternalOpts hi = io;
-    hi.no_split = true;
-    const uint64_t b0 = (batch + 1) / 2;
-    int rc2 = create_plan(n, b0, device_id, &ho, hi, &p->half[0]);
-    if (rc2) return bail(rc2);
-    rc2 = create_plan(n, batch - b0, device_id, &ho, hi, &p->half[1]);
-    if (rc2) return bail(rc2);
-    (void)hipSetDevice(device_id);
-    hipError_t e2 = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
-    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
-    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
-    if (e2 != hipSuccess) return bail(hip_fail(e2, "stream / events of a split plan"));
-    (void)hipSetDevice(prev);
-    *out = p;
-    return TFFT_OK;
-  };
   if (order == TFFT_ORDER_TRANSPOSED && inner == 1 && tfft_plan_transposed_n2(n)) {
-    // (not split: measured 329 -> 331 Gsamples/s at 2^20 x 1024, nothing; its second pass is a single-pass kernel whose
-    // workgroups are short-lived already)
     rc = create_transposed(p, opts, device_id);
     if (rc) return bail(rc);
     (void)hipSetDevice(prev);
@@ -1061,7 +992,6 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   // ---- pass list (plan_passes: pure host logic, also behind tfft_plan_describe)
   plan_passes(n, inner, pvariant, p->passes);
   if (io.group_shift && !single_kernel(p)) return bail(fail(TFFT_ERR_ARG, "grouped addressing needs a single-kernel plan"));
-  if (!single_kernel(p) && p->passes.size() >= 2 && inner == 1 && !tw4 && split_allowed()) return make_split();
   if (tw4 && !(p->passes.size() == 1 && p->passes[0].kind == PassKind::Col256))
     return bail(fail(TFFT_ERR_ARG, "fourstep_n: this (n, inner) does not plan as one column pass"));
   k4096::TableScale ts;
@@ -1150,15 +1080,6 @@ void tfft_plan_destroy(tfft_plan* p) {
   if (!p) return;
   tfft_plan_destroy(p->sub_col);
   tfft_plan_destroy(p->sub_row);
-  for (tfft_plan* h : p->half)
-    if (h) {
-      h->ws = nullptr;                  // (a slice of this plan's workspace)
-      h->ws_owned = false;
-      tfft_plan_destroy(h);
-    }
-  if (p->side) (void)hipStreamDestroy(p->side);
-  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   if (p->d_tables) (void)hipFree(p->d_tables);
   if (p->d_tw_lo) (void)hipFree(p->d_tw_lo);
   if (p->d_tw_hi) (void)hipFree(p->d_tw_hi);
@@ -1193,13 +1114,11 @@ int tfft_plan_describe(uint64_t n, uint64_t inner, int variant, char* buf, size_
 // passes over the data (a narrow column pass with a ragged batch takes two launches for its one pass)
 int tfft_plan_num_launches(const tfft_plan* p) {
   if (!p) return 0;
-  if (p->half[0]) return tfft_plan_num_launches(p->half[0]);       // passes over the data, not launches per half
   if (p->sub_col) return tfft_plan_num_launches(p->sub_col) + tfft_plan_num_launches(p->sub_row);
   return static_cast<int>(p->passes.size());
 }
 
 size_t tfft_plan_workspace_bytes(const tfft_plan* p) {
-  if (p && p->half[0]) return tfft_plan_workspace_bytes(p->half[0]) + tfft_plan_workspace_bytes(p->half[1]);
   if (p && p->sub_col) return static_cast<size_t>(p->batch) * p->n * 4;   // planar intermediate [RE | IM]
   if (!p || p->passes.size() == 1) {
     // a single pass needs scratch only when asked to run in place
@@ -1284,8 +1203,6 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
   static const bool no_fuse = std::getenv("TFFT_2D_NO_FUSE") != nullptr;   // experiment knob
   p->fused = (rows == 4096 && cols == 4096 && batch * 512 <= 0xffffffffull && !no_fuse);
   int rc;
-  // (two halves of the image batch on two streams, as tfft_plan::half does for long 1D transforms, were measured on the fused
-  // plan: 3.66 -> 3.92 ms at batch 64; not done)
   if (p->fused) {
     // pass 1 (k4096r.hpp, ROWS): radix-8 column butterfly over the rows r0 + 512 i, fused with the 4096-point row
     // transforms; it only needs the 4096 kernel's constant tables, which a (4096, 1) plan owns.
@@ -1504,7 +1421,6 @@ int tfft_synth_uniform(void* re, void* im, uint64_t n, uint64_t batch, uint64_t 
 
 const char* tfft_plan_kernel_name(const tfft_plan* p) {
   if (!p) return "";
-  if (p->half[0]) return tfft_plan_kernel_name(p->half[0]);
   if (p->sub_col) return tfft_plan_kernel_name(p->sub_col);
   switch (p->passes[0].kind) {
     case PassKind::K4096: return "fft4096_kernel";
@@ -1524,7 +1440,6 @@ double tfft_plan_algorithmic_bytes(const tfft_plan* p) {
 
 double tfft_plan_mfma_flops(const tfft_plan* p) {
   if (!p) return 0.0;
-  if (p->half[0]) return tfft_plan_mfma_flops(p->half[0]) + tfft_plan_mfma_flops(p->half[1]);
   if (p->sub_col) return tfft_plan_mfma_flops(p->sub_col) + tfft_plan_mfma_flops(p->sub_row);
   // one radix-16 MFMA stage = 16 tiles x 2 MFMA(16x16x32) x 16384 flop per 4096 samples = 128 flop/sample
   double stages = 0;

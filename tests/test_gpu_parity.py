@@ -637,11 +637,10 @@ def test_layout_adapters_roundtrip(tf, torch):
     assert float((got - want).abs().pow(2).sum().sqrt() / want.abs().pow(2).sum().sqrt()) < REL_L2_TOL
 
 
-@pytest.mark.parametrize("n,batch", [(1 << 16, 8), (1 << 13, 6), (1 << 17, 4), (1 << 21, 1), (1 << 20, 128), (1 << 22, 33)])
+@pytest.mark.parametrize("n,batch", [(1 << 16, 8), (1 << 13, 6), (1 << 17, 4), (1 << 21, 1)])
 def test_exec_is_graph_capturable(tf, torch, n, batch):
     """tfft_exec allocates nothing once the workspace is set, so a pass chain can be captured in a HIP graph
-    (column passes, the single-pass 8192 kernel, radix-512 passes, fused tails; the last two cases are plans that run as two
-    half-batches on two streams: the side stream joins the capture through the fork event)."""
+    (column passes, the single-pass 8192 kernel, radix-512 passes, fused tails)."""
     x = (torch.rand(batch * 2 * n, device="cuda") * 2 - 1).half()
     y = torch.zeros_like(x)
     plan = tf.TfftPlan(n, batch, 0, preserve_input=True)
@@ -661,42 +660,6 @@ def test_exec_is_graph_capturable(tf, torch, n, batch):
     graph.replay()
     torch.cuda.synchronize()
     assert bool((y == ref).all())
-
-
-def test_split_plan_matches_single_stream_plan(tf, torch, orc):
-    """A multi-pass plan over >= 2^26 samples runs as two half-batches on two streams (tfft.hip, tfft_plan::half): same bits
-    as the single-stream plan (variant bit 268435456), for even and odd batches, out of place, in place and with
-    preserve_input; ordering against the caller's stream holds (the input is produced and the output consumed on it
-    without any synchronisation in between); two sampled transforms against the oracle."""
-    for n, batch in ((1 << 20, 128), (1 << 18, 513), (1 << 22, 33)):
-        gen = torch.Generator(device="cuda").manual_seed(n + batch)
-        x = (torch.rand(batch * 2 * n, device="cuda", generator=gen) * 2 - 1).half()
-        single = tf.TfftPlan(n, batch, 0, preserve_input=True, variant=268435456)
-        want = torch.empty_like(x)
-        single.exec(x, x[n:], want, want[n:])
-        torch.cuda.synchronize()
-        for kw in ({"preserve_input": True}, {}):
-            plan = tf.TfftPlan(n, batch, 0, **kw)
-            assert plan.workspace_bytes == single.workspace_bytes
-            s = torch.cuda.Stream()
-            with torch.cuda.stream(s):
-                src = torch.zeros_like(x)
-                src.copy_(x)                                    # producer on the caller's stream, no sync
-                y = torch.full_like(x, float("nan"))
-                plan.exec(src, src[n:], y, y[n:], stream=s.cuda_stream)
-                got = y.clone()                                 # consumer on the caller's stream, no sync
-            torch.cuda.synchronize()
-            assert bool((got == want).all()), (n, batch, kw)
-        z = x.clone()
-        tf.TfftPlan(n, batch, 0).exec(z, z[n:], z, z[n:])       # in place
-        torch.cuda.synchronize()
-        assert bool((z == want).all()), (n, batch)
-        for b in (0, batch - 1):
-            blk = x[b * 2 * n:(b + 1) * 2 * n].cpu().numpy()
-            e_re, e_im = orc.dft64(blk[None, :n], blk[None, n:])
-            o = want[b * 2 * n:(b + 1) * 2 * n].cpu().numpy().astype(np.float64)
-            exact = e_re[0] + 1j * e_im[0]
-            assert np.linalg.norm(o[:n] + 1j * o[n:] - exact) / np.linalg.norm(exact) <= REL_L2_TOL
 
 
 def test_2d_inverse_round_trip(tf, torch):

@@ -1,4 +1,7 @@
-"""Sub-batches on several HIP streams: does overlapping the passes of different sub-batches (tails filled, intermediate of a
+"""(Historical: the gain this shows, +3..+8 % for two half-batches on two streams, came from workgroups idling behind the slow
+residue class of the plain grid stride; with the rotated work distribution, k4096::Rotor, it is gone and the library does
+not split batches.)
+Sub-batches on several HIP streams: does overlapping the passes of different sub-batches (tails filled, intermediate of a
 sub-batch possibly still in the 256-MiB Infinity Cache for its next pass) beat one plan over the whole batch?
 usage: [TFFT_AB_LIB=libtfft_x.so] python tools/exp_streams_chunked.py N batch chunk:streams [chunk:streams ...]"""
 import os, sys, time
