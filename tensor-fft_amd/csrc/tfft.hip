@@ -178,15 +178,15 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
     if (col_ok) n256 = lg / 8;
     int rem = lg - 8 * n256;
     std::vector<int> radices(n256, 256);
-    // Radix-512 / radix-1024 column passes where they save a whole pass (2^15 = 512 x 64, 2^17 = 512 x 256, 2^19 = 1024 x 512,
-    // 2^20 = 1024 x 1024, 2^26 = 1024 x 256 x 256, 2^28 .. 2^30 in three passes). Contiguous axis, 2^16 .. 2^30, default
+    // Radix-512 / radix-1024 column passes where they save a whole pass (2^15 = 512 x 64, 2^17 = 512 x 256, 2^19 = 512 x 1024,
+    // 2^20 = 1024 x 1024, 2^26 = 512 x 512 x 256, 2^28 .. 2^30 in three passes). Contiguous axis, 2^16 .. 2^30, default
     // variant: the split measured fastest among all orders of all splits with the fewest passes (tools/plan_scan.py,
-    // profiles/r2_plan_scan.txt). The wide radices go FIRST: a radix-1024 first pass writes 2-KiB runs per column, and a
-    // radix-256 last pass keeps its 256-byte row segments.
+    // profiles/r2_plan_scan.txt, last run: with the rotated work distribution of k4096::Rotor the candidates lie within a few
+    // per cent of each other).
     static const int kColSplit[15][3] = {
-        {1024, 0, 0},     {512, 256, 0},    {1024, 256, 0},    {1024, 512, 0},     {1024, 1024, 0},      // 2^16 .. 2^20
-        {256, 256, 0},    {256, 256, 0},    {512, 256, 0},     {1024, 256, 0},     {1024, 1024, 0},      // 2^21 .. 2^25
-        {1024, 256, 256}, {1024, 512, 256}, {256, 1024, 1024}, {1024, 512, 1024},  {1024, 1024, 1024}};  // 2^26 .. 2^30
+        {256, 256, 0},    {512, 256, 0},    {512, 512, 0},     {512, 1024, 0},     {1024, 1024, 0},      // 2^16 .. 2^20
+        {512, 512, 0},    {512, 512, 0},    {512, 512, 0},     {512, 1024, 0},     {1024, 1024, 0},      // 2^21 .. 2^25
+        {512, 512, 256},  {1024, 512, 256}, {256, 1024, 1024}, {1024, 512, 1024},  {1024, 1024, 1024}};  // 2^26 .. 2^30
     const bool use512 = col_ok && inner == 1 && lg >= 15 && !(variant & 8388608);
     const bool use1024 = col_ok && inner == 1 && lg >= 16 && !(variant & 33554432);
     if (use512 && use1024 && lg >= 16 && lg <= 30 && !(variant & 134217728)) {

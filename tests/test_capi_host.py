@@ -156,14 +156,15 @@ def test_planner_pass_counts():
     assert tf.plan_describe(1 << 12) == "k4096:4096"
     assert tf.plan_describe(1 << 15) == "k4096r:8"
     assert tf.plan_describe(1 << 17) == "col:512+tw col:256"
-    assert tf.plan_describe(1 << 16) == "col:1024+tw autosort:64-tw"
-    assert tf.plan_describe(1 << 19) == "col:1024+tw col:512"
+    assert tf.plan_describe(1 << 16) == "col:256+tw col:256"
+    assert tf.plan_describe(1 << 19) == "col:512+tw col:1024"
     assert tf.plan_describe(1 << 20) == "col:1024+tw col:1024"
     assert tf.plan_describe(1 << 20, 1, 33554432) == "col:256+tw col:256+tw autosort:16-tw"
     assert tf.plan_describe(1 << 28) == "col:256+tw col:1024+tw col:1024"
     assert tf.plan_describe(1 << 28, 1, 134217728) == "col:1024+tw col:1024+tw col:256"
     assert tf.plan_describe(1 << 27, 1, 33554432) == "col:512+tw col:512+tw col:512"
-    assert tf.plan_describe(1 << 26) == "col:1024+tw col:256+tw col:256"
+    assert tf.plan_describe(1 << 26) == "col:512+tw col:512+tw col:256"
+    assert tf.plan_describe(1 << 21) == "col:512+tw col:512+tw autosort:8-tw"
     assert tf.plan_describe(4096, 4096) == "col:256+tw autosort:16-tw"          # 2D column pass (general shapes)
     assert tf.plan_describe(512, 4096, 67108864) == "col:512"                    # second pass of the fused 4096^2 plan
     assert tf.plan_describe(1 << 13, 1, 16777216) == "col:256+tw autosort:32-tw"
