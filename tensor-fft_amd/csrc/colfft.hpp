@@ -75,6 +75,9 @@ struct Args {
   // twiddle tables are then built for M, the length of the whole four-step transform, not for this pass's radix):
   // the w_N^(k1 n2) step of a transform split as N = N1 N2 (transposed-order plans, local passes of a distributed one)
   uint64_t tw4_col0;
+  // measurement hook (tools/exp_wg_end_times.py; null in normal use): wall_clock64 at entry [i] and exit [8192 + i] and the XCC
+  // id [16384 + i] of workgroup i of the radix-1024 pass
+  unsigned long long* wg_times;
 };
 
 // twiddle forms of a column pass: none, the next autosort pass's input twiddles, the four-step twiddle

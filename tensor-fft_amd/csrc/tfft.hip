@@ -481,6 +481,9 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   a.tw_scale = ps.tw_scale;
   a.comb_scale = ps.scale;
   a.tw4_col0 = p->tw4_col0;
+  a.wg_times = nullptr;
+  if (debug_variants_enabled())          // measurement hook of tools/exp_wg_end_times.py
+    if (const char* e = std::getenv("TFFT_WG_TIMES_PTR")) a.wg_times = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0));
   a.copy_only = (p->variant & 65536) ? 1u : 0u;
   a.out_row_shift = p->out_row_shift;
   a.out_sub_shift = p->out_sub_shift;

@@ -1,17 +1,16 @@
-"""When and where do the workgroups of a radix-1024 column pass run? Needs a debug build of the library (libtfft_dbg.so, not
-part of the product) that records wall_clock64() at entry / exit and the XCC id per workgroup.
-    [TFFT_COLWG_ITERS=4] python tools/exp_wg_end_times.py"""
+"""When and where do the workgroups of a radix-1024 column pass run? The kernel records wall_clock64() at entry / exit and the
+XCC id per workgroup into the buffer named by TFFT_WG_TIMES_PTR (honoured only with TFFT_DEBUG_VARIANTS=1; both set here).
+    [TFFT_COLWG_ITERS=4] [TFFT_VARIANT=256] python tools/exp_wg_end_times.py        (256 = first pass only)
+profiles/r2_wg_end_times.txt holds the runs that found the slow residue class."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import numpy as np
 dbg = torch.zeros(3 * 8192, dtype=torch.int64, device="cuda")
-os.environ["TFFT_DBG_PTR"] = str(dbg.data_ptr())
+os.environ["TFFT_WG_TIMES_PTR"] = str(dbg.data_ptr())
 os.environ["TFFT_NO_SPLIT"] = "1"
 os.environ["TFFT_DEBUG_VARIANTS"] = "1"
 import tensor_fft_amd as tf
-from tensor_fft_amd import capi
-capi._LIB_NAME = "libtfft_dbg.so"
 n, b = 1 << 20, 1024
 x = torch.empty(b * 2 * n, dtype=torch.float16, device="cuda"); tf.synth_uniform(x, x[n:], n, b)
 y = torch.empty_like(x)
