@@ -240,10 +240,10 @@ __device__ __forceinline__ f4 mfma(h8 a, h8 b) {
 // ms: 2^20 x 1024 295 -> 346 Gsamples/s). Rotating makes every workgroup take all eight classes in turn.
 struct Rotor {
   uint32_t g, n, pos, rnd;
-  __device__ Rotor(uint32_t block, uint32_t grid) : g(block), n(grid), pos(block), rnd(0) {}
-  __device__ uint32_t item() const { return rnd * n + pos; }
-  __device__ uint32_t peek() const { return (rnd + 1) * n + (pos + 1 == n ? 0 : pos + 1); }      // next round's item
-  __device__ void advance() {
+  __host__ __device__ Rotor(uint32_t block, uint32_t grid) : g(block), n(grid), pos(block), rnd(0) {}
+  __host__ __device__ uint32_t item() const { return rnd * n + pos; }
+  __host__ __device__ uint32_t peek() const { return (rnd + 1) * n + (pos + 1 == n ? 0 : pos + 1); }      // next round's item
+  __host__ __device__ void advance() {
     ++rnd;
     pos = (pos + 1 == n) ? 0 : pos + 1;
   }

@@ -262,6 +262,16 @@ def test_cxx_shim_tuner_file_overload_keeps_column_six(tmp_path, monkeypatch):
         assert [str(p._variant), str(p.amount_of_r16_steps_), str(p.amount_of_r2_steps_), str(p.base_fft_mode_)] == run(n)[1:]
 
 
+def test_rotor_covers_every_item_once(tmp_path):
+    """k4096::Rotor, the rotated work distribution of the persistent kernels (DESIGN.md 3.3), on the host: every item exactly
+    once for ragged grids and totals, look-ahead = next item, all residues mod 8 per workgroup."""
+    import subprocess
+
+    exe = str(tmp_path / "rotor_host")
+    _hipcc_host(os.path.join(ROOT, "tests", "cxx", "rotor_host.cpp"), exe)
+    assert subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip() == "ok"
+
+
 def test_reference_style_mains_compile_against_the_shim(tmp_path):
     """A main() that makes the reference's calls in the reference's order (ExampleBatchFFT.cu:20-85, ExampleSingleFFT.cu)
     builds against include/tensor_fft.hpp with hipcc. (Running it needs a GPU: tests/test_gpu_parity.py.)"""
