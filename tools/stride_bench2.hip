@@ -1,7 +1,9 @@
 // stride_bench2.hip — bandwidth of column-pass tiles as a function of the row-segment width: a workgroup tile is
 // ROWS rows x SEG bytes per plane (64 KiB per plane in all cases), rows `pitch` bytes apart, in and out.
 // SEG = 256: the radix-256 column kernel today; SEG = 128 / 64: what a 512- / 1024-row column kernel would move.
-// `pair`: adjacent column blocks go to workgroups blockIdx and blockIdx + 8 (same XCD) instead of blockIdx + 1.
+// `pair` = 1: adjacent column blocks go to workgroups blockIdx and blockIdx + 8 (same XCD) instead of blockIdx + 1.
+// `pair` = 2: the rotated work distribution of the library (k4096::Rotor: round t, workgroup g -> tile t G + (g + t) mod G), so
+// that no workgroup is pinned to one residue class of the tile index modulo 8.
 // build: hipcc -O3 --offload-arch=gfx950 -o tools/stride_bench2 tools/stride_bench2.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,9 +17,10 @@ __global__ __launch_bounds__(512) void k(const uint8_t* in, uint8_t* out, uint64
   constexpr int RPI = 1024 / SEG;              // rows per wave instruction
   constexpr int LPR = SEG / 16;                // lanes per row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+  uint32_t rnd = 0, pos = blockIdx.x;
+  for (uint32_t t = blockIdx.x; t < total; ) {
     uint32_t blk = t;
-    if (pair) {   // t = 16 a + 8 b + c  ->  column block 16 a + 2 c + b: blocks 2c and 2c+1 run as t and t + 8
+    if (pair == 1) {   // t = 16 a + 8 b + c  ->  column block 16 a + 2 c + b: blocks 2c and 2c+1 run as t and t + 8
       const uint32_t a = t >> 4, b = (t >> 3) & 1, c = t & 7;
       blk = 16 * a + 2 * c + b;
     }
@@ -37,6 +40,13 @@ __global__ __launch_bounds__(512) void k(const uint8_t* in, uint8_t* out, uint64
       __builtin_nontemporal_store(vr[i], reinterpret_cast<u4*>(dst + r * pitch + 16 * (lane % LPR)));
       __builtin_nontemporal_store(vi[i], reinterpret_cast<u4*>(dst + plane + r * pitch + 16 * (lane % LPR)));
     }
+    ++rnd;
+    if (pair == 2) {
+      pos = (pos + 1 == gridDim.x) ? 0 : pos + 1;
+      t = rnd * gridDim.x + pos;
+    } else {
+      t += gridDim.x;
+    }
   }
 }
 
@@ -55,7 +65,7 @@ void run(const uint8_t* in, uint8_t* out, uint64_t pitch, uint64_t plane_bytes, 
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   printf("  seg %3d B x %4d rows, pitch %7llu B, %s: %8.1f us  %6.0f GB/s\n", SEG, ROWS, (unsigned long long)pitch,
-         pair ? "paired on one XCD" : "neighbours on different XCDs", ms * 1e3, 4.0 * total * 65536 / ms * 1e-6);
+         pair == 2 ? "rotated assignment" : (pair ? "paired on one XCD" : "neighbours on different XCDs"), ms * 1e3, 4.0 * total * 65536 / ms * 1e-6);
   (void)nt_off;
 }
 
@@ -65,7 +75,7 @@ int main() {
   hipMalloc(&in, 2 * plane); hipMalloc(&out, 2 * plane);
   hipMemset(in, 1, 2 * plane);
   for (uint64_t pitch : {2048ull, 8192ull, 131072ull}) {
-    for (int pair = 0; pair < 2; ++pair) {
+    for (int pair = 0; pair < 3; ++pair) {
       run<256>(in, out, pitch, plane, pair, false);
       run<128>(in, out, pitch, plane, pair, false);
       run<64>(in, out, pitch, plane, pair, false);
