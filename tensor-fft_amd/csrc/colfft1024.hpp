@@ -475,6 +475,9 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // F: read out; the next block's copy-in may overwrite the images
   }
+  // the last iteration's look-ahead (table LDS-DMA, register loads of its own block again) must have landed before the
+  // workgroup gives its LDS back
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (a.wg_times && tid == 0 && blockIdx.x < 8192) {
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
