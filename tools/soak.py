@@ -38,6 +38,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     cases = fails = 0
+    t_last = time.time()
     kinds = {}
     while time.time() < t_end:
         kind = str(rng.choice(["plain", "plain", "strided", "transposed", "fourstep", "scale", "variant"]))
@@ -114,6 +115,9 @@ def main():
             print(f"FAIL {kind} n=2^{lg} inner={inner} batch={batch} pad={pad} in_place={in_place} preserve={preserve} {kw}: {e}", flush=True)
         cases += 1
         kinds[kind] = kinds.get(kind, 0) + 1
+        if time.time() - t_last > 60:             # (a long silent run looks hung to a job watchdog)
+            t_last = time.time()
+            print(f"... {cases} cases, {fails} failure(s)", flush=True)
         del blk, keep
     print(f"soak: {cases} cases ({kinds}), {fails} failure(s), seed {args.seed}")
     return 1 if fails else 0
