@@ -150,9 +150,13 @@ enum { TFFT_SCALE_SEQUENTIAL = 0, TFFT_SCALE_NONE = 1, TFFT_SCALE_ONCE = 2 };
  *                the [N1][N2] matrix of the four-step algorithm left un-transposed (the order DistributedFFT1D's
  *                "transposed" layout has). For 2^16 <= N <= 2^24 this takes TWO passes over HBM (one strided radix-N1
  *                column pass that also applies w_N^(k1 n2), one contiguous N2-point pass) where natural order needs
- *                three from 2^19 on: for callers that multiply spectra pointwise and transform back, or that index
- *                the spectrum through the map above. Lengths without a two-pass split fall back to NATURAL
- *                (tfft_plan_transposed_n2(n) == 0). Needs a workspace (tfft_plan_workspace_bytes). */
+ *                three from 2^21 on (2^16 .. 2^20 take two passes either way): for callers that only reduce over the
+ *                spectrum or index it through the map above. There is no transposed-order INPUT: tfft_exec_inverse on
+ *                such a plan takes natural-order input like any other plan, so "multiply spectra and transform back"
+ *                still needs natural order. Contiguous axis only (inner > 1 is refused). Lengths without a two-pass
+ *                split fall back to NATURAL (tfft_plan_transposed_n2(n) == 0). variant: only the column-pass bits
+ *                262144 / 524288 and the single-kernel bits of the N2 kernel (1 / 2 / 8 / 16, 1048576) are honoured,
+ *                others are refused. Needs a workspace (tfft_plan_workspace_bytes). */
 enum { TFFT_ORDER_NATURAL = 0, TFFT_ORDER_TRANSPOSED = 1 };
 
 /* Host only. N2 of the TRANSPOSED order for length n (0: no two-pass split, natural order is produced). */

@@ -69,8 +69,14 @@ class PlanOpts(ctypes.Structure):
     ]
 
 
+def _debug_requested():
+    return os.environ.get("TFFT_DEBUG_VARIANTS") == "1" and os.environ.get("TFFT_USE_DEBUG_LIB") == "1"
+
+
 def lib_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    """libtfft.so. Only the measurement drivers under tools/ (which set TFFT_DEBUG_VARIANTS=1 and TFFT_USE_DEBUG_LIB=1
+    before the first load) get libtfft_debug.so, the -DTFFT_DEBUG_KERNELS build with the timing-only kernels."""
+    return os.path.join(_HERE, "libtfft_debug.so" if _debug_requested() else _LIB_NAME)
 
 
 _lib = None

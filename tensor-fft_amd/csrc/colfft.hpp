@@ -57,7 +57,9 @@ struct Args {
   uint64_t n_over_t;                // N / T
   double inv_t;                     // 1 / T
   uint64_t n_mask;                  // N - 1
+#ifdef TFFT_DEBUG_KERNELS
   uint32_t copy_only;               // timing experiment (WRONG output): move the image straight back out
+#endif
   // radix-512 columns-in-registers pass as the second pass of a 2D transform (see k4096r.hpp, ROWS): output row k of
   // batch entry e goes to (e >> out_sub_shift) * out_stride + (e & mask) * out_sub_stride + (k << out_row_shift) rows
   uint32_t out_row_shift;
@@ -75,9 +77,11 @@ struct Args {
   // twiddle tables are then built for M, the length of the whole four-step transform, not for this pass's radix):
   // the w_N^(k1 n2) step of a transform split as N = N1 N2 (transposed-order plans, local passes of a distributed one)
   uint64_t tw4_col0;
+#ifdef TFFT_DEBUG_KERNELS
   // measurement hook (tools/exp_wg_end_times.py; null in normal use): wall_clock64 at entry [i] and exit [8192 + i] and the XCC
   // id [16384 + i] of workgroup i of the radix-1024 pass
   unsigned long long* wg_times;
+#endif
 };
 
 // twiddle forms of a column pass: none, the next autosort pass's input twiddles, the four-step twiddle
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TFFT_DEBUG_KERNELS
     if (a.copy_only) {
       // data-movement ceiling of this kernel's access pattern: same 32-byte-per-row pieces out as in
       uint16_t* const c_re = a.out_re + bidx * a.out_stride + m0;
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft256_kernel(Args a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       continue;
     }
+#endif
 
     // ---- stage 1: D1_ilo[ka = 4g + r][column = lane & 15]
     uint32_t pr[8][4], pi[8][4];
@@ -481,6 +487,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // A: the whole block is in LDS
 
+#ifdef TFFT_DEBUG_KERNELS
     if (MODE == kColsInRegs && a.copy_only) {
       // timing experiment (WRONG output): the image goes straight back out through the row stores below
       uint16_t* const c_re = a.out_re + bidx * a.out_stride;
@@ -503,6 +510,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
       __builtin_amdgcn_s_barrier();
       continue;
     }
+#endif
 
     // ---- stage 1
     uint32_t pr[8][4], pi[8][4];

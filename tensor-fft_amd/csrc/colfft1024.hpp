@@ -150,7 +150,9 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
   // -0.3 % at 2^25)
   Rotor rot(blockIdx.x, gridDim.x);
   const uint32_t bid0 = rot.item();
+#ifdef TFFT_DEBUG_KERNELS
   if (a.wg_times && tid == 0 && blockIdx.x < 8192) a.wg_times[blockIdx.x] = wall_clock64();
+#endif
   if (bid0 < total) issue_loads(bid0);
 
   // B_q of the first round, then E_1 / D_1. Columns in registers: [ka >> 1][2 (ka & 1) + {0, 1}] = columns {0,1}, {2,3} of
@@ -478,12 +480,14 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
   // the last iteration's look-ahead (table LDS-DMA, register loads of its own block again) must have landed before the
   // workgroup gives its LDS back
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TFFT_DEBUG_KERNELS
   if (a.wg_times && tid == 0 && blockIdx.x < 8192) {
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     a.wg_times[8192 + blockIdx.x] = wall_clock64();
     a.wg_times[16384 + blockIdx.x] = xcc;
   }
+#endif
 }
 
 }  // namespace colfft

@@ -254,10 +254,16 @@ struct Rotor {
 //               current one out of LDS, so it flies under stages 2/3 and the stores.
 //   kStageOut   stage the spectrum through the wave's LDS region and store it as
 //               full 1-KiB rows (mutually exclusive with kPrefetch: same LDS bytes).
-//   kFakeStore  timing experiment only (WRONG output): coalesced stores of the raw registers.
 //   kNonTemporal  nt cache policy on the streamed loads and stores (every byte is touched once).
-//   kNoCompute    timing experiment only (WRONG output): copy the LDS image straight out (data-movement ceiling).
-enum : int { kPrefetch = 1, kStageOut = 2, kFakeStore = 4, kNonTemporal = 8, kNoCompute = 64 };
+// Only with -DTFFT_DEBUG_KERNELS (libtfft_debug.so for the drivers under tools/; the shipped library has no such code):
+//   kFakeStore  timing experiment only (WRONG output): coalesced stores of the raw registers.
+//   kNoCompute  timing experiment only (WRONG output): copy the LDS image straight out (data-movement ceiling).
+enum : int { kPrefetch = 1, kStageOut = 2, kNonTemporal = 8 };
+#ifdef TFFT_DEBUG_KERNELS
+enum : int { kFakeStore = 4, kNoCompute = 64 };
+#else
+enum : int { kFakeStore = 0, kNoCompute = 0 };     // (V & 0): those branches do not exist in the shipped library
+#endif
 
 // LDS-DMA of one transform: 16 x global_load_lds_dwordx4 hidden from the compiler's
 // wait-count bookkeeping (inline asm), so that the only waits are the counted ones below.
@@ -357,7 +363,11 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
 
   bool first = true;
 
-  for (; b < batch; b += stride_b) {
+  // Loop shape: the only exits lie BEFORE an iteration's look-ahead copy is issued (`if (nb >= batch) break`), so no
+  // control-flow path leads from an LDS-DMA to the end of the program without passing the s_waitcnt vmcnt(0) at the loop
+  // top (tools/isa_lint.py checks exactly that on the disassembly; the prefetch variants, whose look-ahead sits in the
+  // middle of the body, drain explicitly behind the loop).
+  for (;;) {
     // The 16 copies of this transform are the oldest outstanding vector-memory operations; with
     // prefetch the previous iteration issued its 16 output stores after them, and vmcnt retires in order.
     if ((V & kPrefetch) && !first)
@@ -385,6 +395,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
         st<V>(f_re + 512 * i + 8 * lane, vr[i]);
         st<V>(f_im + 512 * i + 8 * lane, vi[i]);
       }
+      if (nb0 >= batch) break;
+      b = nb0;
       continue;
     }
     // ---- stage 1: D1_n1[k0 = 4g + r][n0 = lane & 15], packed over tile pairs
@@ -506,13 +518,17 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
         st<V>(fft_im + 512 * i + 8 * lane, vi);
       }
     }
+    if (nb >= batch) break;
     if (!(V & kPrefetch)) {
       if (V & kStageOut) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image read out before reuse
-      if (nb < batch)
-        dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(nb)),
-               reinterpret_cast<const uint8_t*>(in_im + in_map.off(nb)), wl_off, lane);
+      dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(nb)),
+             reinterpret_cast<const uint8_t*>(in_im + in_map.off(nb)), wl_off, lane);
     }
+    b = nb;
   }
+  // prefetch / timing-only variants: their look-ahead copy is issued under a condition in the middle of the body; make the
+  // drain explicit (costs the default kernel nothing: it is not instantiated with these bits)
+  if (V & (kPrefetch | kNoCompute)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace k4096

@@ -58,10 +58,19 @@ constexpr int kVarK4096 = 1 | 2 | 8 | 16;
 constexpr int kVarDebug = 4 | 64 | 128 | 65536 | (15 << 8);
 constexpr int kVarTuner = kVarK4096 | 32 | 4096 | 8192 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 |
                           8388608 | 16777216 | 33554432 | 67108864 | 134217728;
+// The shipped libtfft.so holds NO timing-only kernel, no environment knob and no measurement hook: all of that is compiled
+// only with -DTFFT_DEBUG_KERNELS (tensor-fft_amd/libtfft_debug.so, built on demand for the drivers under tools/), and even
+// there the debugging bits need TFFT_DEBUG_VARIANTS=1 in the environment of the process that creates the plan.
+#ifdef TFFT_DEBUG_KERNELS
+constexpr bool kDebugBuild = true;
 inline bool debug_variants_enabled() {
   const char* e = std::getenv("TFFT_DEBUG_VARIANTS");
   return e && e[0] == '1' && e[1] == 0;
 }
+#else
+constexpr bool kDebugBuild = false;
+inline bool debug_variants_enabled() { return false; }
+#endif
 
 // Opt-in to more than 64 KiB of dynamic LDS, once per (kernel, device). The outcome is STICKY: a failure is returned on
 // every later call too (a std::call_once would report it once and then launch without the attribute). Plans run this
@@ -234,6 +243,7 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
     }
     // experiment knob (honoured only with TFFT_DEBUG_VARIANTS=1): TFFT_PLAN_COLS="512,512,256" replaces the column passes of a
     // contiguous-axis plan by the given radices in the given order (their product must divide n; the tail follows as usual)
+#ifdef TFFT_DEBUG_KERNELS
     if (col_ok && inner == 1 && lg >= 16 && debug_variants_enabled()) {
       if (const char* e = std::getenv("TFFT_PLAN_COLS")) {
         std::vector<int> cols;
@@ -254,6 +264,7 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
         }
       }
     }
+#endif
     for (; rem >= 4; rem -= 4) radices.push_back(16);
     if (rem) radices.push_back(1 << rem);
     // a radix-16 pass followed by a radix-2 / radix-4 pass behind a column pass fuses into one radix-32 / radix-64
@@ -271,7 +282,7 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
       const int R = radices[i];
       const bool last = (i + 1 == radices.size());
       if (R >= 256) {
-        const bool no_tw = variant & 128;   // debugging aid: WRONG results, timing/determinism only
+        const bool no_tw = kDebugBuild && (variant & 128);   // debugging aid: WRONG results, timing/determinism only
         passes.push_back(Pass{PassKind::Col256, R, ns, !last && !no_tw, false, last ? 0 : radices[i + 1]});
       } else {
         const bool prev_col = i > 0 && radices[i - 1] >= 256;
@@ -285,9 +296,16 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
 // Grid of a grid-stride ("persistent") kernel whose workgroups each own `iters` work items per wave slot: at least one
 // workgroup per CU's worth when there is that much work, otherwise blocks_needed / iters so that the hardware
 // dispatcher hands out workgroups as CUs drain (keeps CUs out of lock-step; see launch_k4096_v).
+// (launch-shape experiment knobs: environment variables in the debug build only; the shipped library takes its launch
+// shapes from the plan, see tfft_plan_opts.launch_iters)
 inline uint32_t env_iters(const char* name, uint32_t dflt) {
+#ifdef TFFT_DEBUG_KERNELS
   const char* e = std::getenv(name);
   return e ? static_cast<uint32_t>(std::max(0, std::atoi(e))) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
 }
 inline uint32_t pick_grid(uint64_t blocks_needed, int num_cus, uint32_t iters) {
   const uint64_t lo = std::min<uint64_t>(blocks_needed, static_cast<uint64_t>(num_cus));
@@ -397,10 +415,13 @@ int launch_k4096(const tfft_plan* p, const void* in_re, const void* in_im, void*
                  k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   // opts.variant: 0 = default (staged, coalesced, non-temporal stores: the fastest measured on MI355X);
   // otherwise a mask of k4096::kPrefetch / kStageOut / kFakeStore / kNonTemporal, with 16 = "none of them".
-  const int v = p->variant == 0 ? (k4096::kStageOut | k4096::kNonTemporal) : (p->variant & (15 | 64));
+  const int v = (p->variant & (15 | 16 | 64)) == 0 ? (k4096::kStageOut | k4096::kNonTemporal) : (p->variant & (15 | 64));
 #define TFFT_V(N) case N: return launch_k4096_v<N>(p, in_re, in_im, out_re, out_im, in_stride, out_stride, s)
   switch (v) {
-    TFFT_V(0); TFFT_V(1); TFFT_V(2); TFFT_V(4); TFFT_V(5); TFFT_V(8); TFFT_V(9); TFFT_V(10); TFFT_V(13); TFFT_V(64); TFFT_V(72); TFFT_V(73);
+    TFFT_V(0); TFFT_V(1); TFFT_V(2); TFFT_V(8); TFFT_V(9); TFFT_V(10);
+#ifdef TFFT_DEBUG_KERNELS      // timing-only instantiations (WRONG output): fake stores / no compute
+    TFFT_V(4); TFFT_V(5); TFFT_V(13); TFFT_V(64); TFFT_V(72); TFFT_V(73);
+#endif
     default: return fail(TFFT_ERR_ARG, "unknown kernel variant");
   }
 #undef TFFT_V
@@ -481,10 +502,12 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   a.tw_scale = ps.tw_scale;
   a.comb_scale = ps.scale;
   a.tw4_col0 = p->tw4_col0;
+#ifdef TFFT_DEBUG_KERNELS
   a.wg_times = nullptr;
   if (debug_variants_enabled())          // measurement hook of tools/exp_wg_end_times.py
     if (const char* e = std::getenv("TFFT_WG_TIMES_PTR")) a.wg_times = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0));
   a.copy_only = (p->variant & 65536) ? 1u : 0u;
+#endif
   a.out_row_shift = p->out_row_shift;
   a.out_sub_shift = p->out_sub_shift;
   a.out_sub_stride = p->out_sub_stride;
@@ -673,7 +696,7 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
     return launch_chain(p->sub_row, w, w_im, out_re, out_im, s);
   }
   int np = static_cast<int>(p->passes.size());
-  if ((p->variant >> 8) & 15) np = std::min(np, (p->variant >> 8) & 15);   // debugging aid: run only the first passes
+  if (kDebugBuild && ((p->variant >> 8) & 15)) np = std::min(np, (p->variant >> 8) & 15);   // debugging aid: run only the first passes
   if (single_kernel(p)) {
     const PassKind kind = p->passes[0].kind;
     const int rc = kind == PassKind::K4096
@@ -759,7 +782,10 @@ int check_variant(uint64_t n, uint64_t inner, int variant) {
   if ((variant & kVarDebug) && !debug_variants_enabled())
     return fail(TFFT_ERR_ARG, "tfft_plan_opts.variant " + std::to_string(variant) +
                                   " holds a timing / debugging bit that produces WRONG or partial results "
-                                  "(4, 64, 128, 65536, p << 8); set TFFT_DEBUG_VARIANTS=1 to allow it");
+                                  "(4, 64, 128, 65536, p << 8)" +
+                                  (kDebugBuild ? std::string("; set TFFT_DEBUG_VARIANTS=1 to allow it")
+                                               : std::string("; this library holds no such kernels (they exist only in a "
+                                                             "-DTFFT_DEBUG_KERNELS build, libtfft_debug.so, with TFFT_DEBUG_VARIANTS=1)")));
   if (n == 4096 && inner <= 1 && !(variant & 32)) {
     const int v = variant & 15;
     if ((variant & 16) && v) return fail(TFFT_ERR_ARG, "variant bit 16 (plain N = 4096 kernel) excludes bits 1, 2, 8");
@@ -884,8 +910,10 @@ int apply_scale_mode(tfft_plan* p, const InternalOpts& io, k4096::TableScale& ts
   if (fin != 1.0) {
     Pass& last = p->passes.back();
     const float f = static_cast<float>(fin);
-    if (last.kind == PassKind::Stockham || last.radix == 512 || last.radix == 1024) last.scale *= f;
-    else if (p->tw4_modulus) last.tw_scale = f;
+    // (a four-step pass first: its epilogue multiplies by tw_scale in every form, whereas the radix-512 four-step read-out is
+    // not the SC instantiation and would drop a factor put on comb_scale)
+    if (p->tw4_modulus) last.tw_scale = f;
+    else if (last.kind == PassKind::Stockham || last.radix == 512 || last.radix == 1024) last.scale *= f;
     else if (p->passes.size() >= 2) p->passes[p->passes.size() - 2].tw_scale = f;
     else if (once_log2 <= 8) ts.g *= fin;
     else return fail(TFFT_ERR_ARG, "TFFT_SCALE_ONCE: this plan has no fp32 multiply to carry the scaling step");
@@ -907,7 +935,13 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   co.out_batch_stride = n;
   co.inner = n2;
   co.preserve_input = 1;
-  co.variant = (p->variant & (262144 | 524288)) | (n1 == 512 ? 67108864 : 0);
+  // tuner bits: the column-pass bits go to the column sub-plan, the single-kernel bits of the N2 kernel to the row sub-plan;
+  // everything else has no meaning for this plan shape and is refused instead of being dropped silently
+  constexpr int kColBits = 262144 | 524288, kRowBits = kVarK4096 | 1048576;
+  if (p->variant & ~(kColBits | kRowBits))
+    return fail(TFFT_ERR_ARG, "tfft_plan_opts.variant " + std::to_string(p->variant) + ": a TFFT_ORDER_TRANSPOSED plan honours only the "
+                              "column-pass bits 262144 / 524288 and the single-kernel bits 1 / 2 / 8 / 16 / 1048576");
+  co.variant = (p->variant & kColBits) | (n1 == 512 ? 67108864 : 0);
   co.scale = mode == TFFT_SCALE_SEQUENTIAL ? TFFT_SCALE_SEQUENTIAL : TFFT_SCALE_NONE;
   co.fourstep_n = n;
   int rc = create_plan(n1, p->batch, device_id, &co, InternalOpts{}, &p->sub_col);
@@ -917,6 +951,7 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   ro.out_batch_stride = n2;
   ro.preserve_input = 1;
   ro.scale = mode;
+  ro.variant = p->variant & ((n2 == 4096 ? kVarK4096 : 0) | ((n2 == 512 || n2 == 1024 || n2 == 2048) ? 1048576 : 0));
   InternalOpts ri;
   ri.group_shift = static_cast<uint32_t>(ilog2(n1));
   ri.in_gstride = n;                       // planar workspace: row b at b * N2 either way
@@ -943,6 +978,8 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   if (scale_mode < TFFT_SCALE_SEQUENTIAL || scale_mode > TFFT_SCALE_ONCE) return fail(TFFT_ERR_ARG, "unknown tfft_plan_opts.scale");
   const int order = opts ? opts->output_order : 0;
   if (order != TFFT_ORDER_NATURAL && order != TFFT_ORDER_TRANSPOSED) return fail(TFFT_ERR_ARG, "unknown tfft_plan_opts.output_order");
+  if (order == TFFT_ORDER_TRANSPOSED && inner > 1)
+    return fail(TFFT_ERR_ARG, "TFFT_ORDER_TRANSPOSED exists for a contiguous axis only (inner <= 1)");
   const uint64_t tw4 = opts ? opts->fourstep_n : 0;
   if (tw4) {
     if (!is_pow2(tw4) || tw4 < n || (n != 256 && n != 512) || inner < 64)
@@ -985,7 +1022,7 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
     g_err = keep;
     return code;
   };
-  if (order == TFFT_ORDER_TRANSPOSED && inner == 1 && tfft_plan_transposed_n2(n)) {
+  if (order == TFFT_ORDER_TRANSPOSED && tfft_plan_transposed_n2(n)) {
     rc = create_transposed(p, opts, device_id);
     if (rc) return bail(rc);
     (void)hipSetDevice(prev);
@@ -1203,7 +1240,11 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
   p->cols = cols;
   p->batch = batch;
   p->device = device_id;
+#ifdef TFFT_DEBUG_KERNELS
   static const bool no_fuse = std::getenv("TFFT_2D_NO_FUSE") != nullptr;   // experiment knob
+#else
+  constexpr bool no_fuse = false;
+#endif
   p->fused = (rows == 4096 && cols == 4096 && batch * 512 <= 0xffffffffull && !no_fuse);
   int rc;
   if (p->fused) {

@@ -264,8 +264,9 @@ def test_debug_variants_are_refused_at_plan_creation(tf, monkeypatch):
         assert "TFFT_DEBUG_VARIANTS" in e.value.message
     with pytest.raises(tf.TfftError):
         tf.TfftPlan(4096, 2, 0, variant=1 << 29)
-    monkeypatch.setenv("TFFT_DEBUG_VARIANTS", "1")
-    assert tf.TfftPlan(1 << 21, 2, 0, variant=1 << 8).num_launches == 3      # tools/pass_breakdown.py still works
+    monkeypatch.setenv("TFFT_DEBUG_VARIANTS", "1")       # the shipped library has no such kernels, whatever the environment says
+    with pytest.raises(tf.TfftError):
+        tf.TfftPlan(1 << 21, 2, 0, variant=1 << 8)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -424,6 +425,28 @@ def test_transposed_output_order(tf, torch, orc, lg, scale):
         assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16)) and np.array_equal(o[:, 1].view(np.uint16), gi.view(np.uint16))
 
 
+def test_transposed_order_variant_bits_and_strided_axis(tf, torch):
+    """a transposed-order plan forwards the tuner bits it can honour (column-pass bits to the column sub-plan,
+    single-kernel bits to the N2 kernel), refuses the others, and refuses a strided axis instead of silently producing
+    natural order."""
+    n = 1 << 20                                            # 256 x 4096: the N2 kernel is the N = 4096 kernel
+    rng = np.random.default_rng(5)
+    re = rng.uniform(-1, 1, (2, n)).astype(np.float16)
+    im = rng.uniform(-1, 1, (2, n)).astype(np.float16)
+    base = _run(tf, torch, re, im, output_order="transposed")
+    for v in (16, 1, 8, 262144, 524288, 524288 | 16):
+        got = _run(tf, torch, re, im, output_order="transposed", variant=v)
+        assert np.array_equal(got[0].view(np.uint16), base[0].view(np.uint16)), v
+        assert np.array_equal(got[1].view(np.uint16), base[1].view(np.uint16)), v
+    for v in (32, 8388608, 33554432, 2097152, 131072):
+        with pytest.raises(tf.TfftError) as e:
+            tf.TfftPlan(n, 2, 0, output_order="transposed", variant=v)
+        assert "TRANSPOSED" in e.value.message
+    with pytest.raises(tf.TfftError) as e:
+        tf.TfftPlan(1 << 16, 2, 0, inner=64, output_order="transposed")
+    assert "contiguous axis" in e.value.message
+
+
 def test_transposed_order_falls_back_outside_its_range(tf, torch, orc):
     for n in (4096, 1 << 15):
         assert tf.transposed_n2(n) == 0
@@ -437,16 +460,20 @@ def test_transposed_order_falls_back_outside_its_range(tf, torch, orc):
 
 @pytest.mark.parametrize("n1,cols,m,col0", [(256, 64, 1 << 14, 0), (256, 256, 1 << 20, 4096 - 256), (256, 1024, 1 << 18, 0),
                                             (512, 64, 1 << 15, 0), (512, 512, 1 << 22, 512 * 7), (256, 8192, 1 << 26, 8192 * 5)])
-def test_fourstep_twiddle_of_the_column_pass(tf, torch, n1, cols, m, col0):
+@pytest.mark.parametrize("scale", ["sequential", "none", "once"])
+def test_fourstep_twiddle_of_the_column_pass(tf, torch, n1, cols, m, col0, scale):
     """fourstep_n = M: column pass output row k, column c times w_M^(k (col0 + c)); the step a distributed transform
-    needs in front of its all-to-all (rank offset col0) and the transposed-order plan uses with col0 = 0."""
+    needs in front of its all-to-all (rank offset col0) and the transposed-order plan uses with col0 = 0. All three
+    scale modes: the radix-512 form once lost its single 1/N under "once" (result 512 x too large)."""
     batch = 2
     rng = np.random.default_rng(n1 + cols)
     re = rng.uniform(-1, 1, (batch, n1, cols)).astype(np.float16)
     im = rng.uniform(-1, 1, (batch, n1, cols)).astype(np.float16)
     dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
     out = torch.full_like(dev, float("nan"))
-    plan = tf.TfftPlan(n1, batch, 0, inner=cols, fourstep_n=m, fourstep_col0=col0)
+    if scale == "none":
+        re, im = (re / 64).astype(np.float16), (im / 64).astype(np.float16)        # unscaled stages: keep fp16 in range
+    plan = tf.TfftPlan(n1, batch, 0, inner=cols, fourstep_n=m, fourstep_col0=col0, scale=scale)
     assert plan.num_launches == 1
     plan.exec(dev, dev[n1 * cols:], out, out[n1 * cols:])
     torch.cuda.synchronize()
@@ -455,7 +482,7 @@ def test_fourstep_twiddle_of_the_column_pass(tf, torch, n1, cols, m, col0):
     k = np.arange(n1)[:, None].astype(np.int64)
     c = (col0 + np.arange(cols))[None, :].astype(np.int64)
     tw = np.exp(-2j * np.pi * ((k * c) % m) / m)
-    want = np.fft.fft(_c(re, im), axis=1) / n1 * tw[None]
+    want = np.fft.fft(_c(re, im), axis=1) / (1 if scale == "none" else n1) * tw[None]
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     assert rel <= REL_L2_TOL, rel
     assert np.abs(got - want).max() < 12 * 2.0 ** -11 * np.abs(want).max()

@@ -4,7 +4,8 @@ import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-os.environ.setdefault("TFFT_DEBUG_VARIANTS", "1")   # experiment driver: timing-only / partial-chain variants allowed
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import debuglib  # noqa: E402,F401  (libtfft_debug.so: timing-only variants and env knobs)
 import __graft_entry__ as g
 g.build()
 import tensor_fft_amd as tf

@@ -9,7 +9,8 @@ import numpy as np
 dbg = torch.zeros(3 * 8192, dtype=torch.int64, device="cuda")
 os.environ["TFFT_WG_TIMES_PTR"] = str(dbg.data_ptr())
 os.environ["TFFT_NO_SPLIT"] = "1"
-os.environ["TFFT_DEBUG_VARIANTS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import debuglib  # noqa: E402,F401  (libtfft_debug.so: timing-only variants and env knobs)
 import tensor_fft_amd as tf
 n, b = 1 << 20, 1024
 x = torch.empty(b * 2 * n, dtype=torch.float16, device="cuda"); tf.synth_uniform(x, x[n:], n, b)

@@ -11,6 +11,9 @@ vectoriser was switched off. This tool makes the properties the 
      them as C. (Instructions count one wait state each, `s_nop N` counts N + 1. LLVM's GCNHazardRecognizer inserts these
      for code it schedules; inline asm is not covered by it, and this check is independent of it.)
 
+  3. no wave ends with an LDS-DMA (global_load_lds_*) possibly in flight: on every control-flow path from such a load to an
+     s_endpgm lies an `s_waitcnt vmcnt(0)` (checked on the disassembly's control-flow graph; pins the fix of commit 6ed7571).
+
 usage: python tools/isa_lint.py [libtfft.so | file.s | disassembly.txt]   (exit code 1 on a finding)
 """
 import os
@@ -127,11 +130,130 @@ def lint_kernel(name, insts):
     return n_mfma, len(pk), findings
 
 
+_ADDR = re.compile(r"^\s+(\S.*?)\s*//\s*([0-9A-Fa-f]{8,}):")
+
+
+def split_kernels_addr(text):
+    """{kernel symbol: [(address, instruction text)]} from an llvm-objdump listing (needs the `// ADDRESS: ENCODING`
+    comments; a plain .s file yields nothing)."""
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(_Z\w+)>:", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+            continue
+        if cur is None:
+            continue
+        m = _ADDR.match(line)
+        if m:
+            kernels[cur].append((int(m.group(2), 16), m.group(1).strip()))
+    return kernels
+
+
+def _sgprs(operand):
+    out = set()
+    for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", operand):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def lint_dma_drain(insts):
+    """3. A wave must not end with LDS-DMA in flight (global_load_lds_* writes LDS asynchronously; a workgroup that retires
+    gives its LDS to the next one while the transfer may still land). Exploration of the kernel's control-flow graph
+    with the abstract state ("an LDS-DMA may be outstanding", known loop-exit flags): global_load_lds sets the first,
+    `s_waitcnt vmcnt(0)` clears it (a partial wait does not); every s_endpgm must be reached with it clear on ALL paths.
+    The one piece of path sensitivity: the structuriser's loop-latch idiom
+        exit path:  s_mov_b64 s[a:b], -1      continue path:  s_mov_b64 s[a:b], 0
+        latch:      s_andn2_b64 vcc, exec, s[a:b] ; s_cbranch_vccz <exit>
+    is followed exactly (an SGPR pair set to 0 / -1 by s_mov_b64 is tracked until something else writes it; exec is taken
+    to be non-zero), because "issue the look-ahead copy, then loop" and "leave" are merged into one latch block by the
+    compiler and only that flag tells them apart. Returns findings."""
+    if not any(t.startswith("global_load_lds") for _, t in insts):
+        return []
+    index = {a: i for i, (a, _) in enumerate(insts)}
+    n = len(insts)
+
+    def branch_target(a, rest):
+        try:
+            off = int(rest.strip().split()[0], 0) & 0xffff
+        except (ValueError, IndexError):
+            return None
+        if off >= 0x8000:
+            off -= 0x10000
+        return index.get(a + 4 + 4 * off)
+
+    bad = set()
+    seen = set()
+    work = [(0, False, frozenset())]
+    while work:
+        st = work.pop()
+        if st in seen:
+            continue
+        seen.add(st)
+        i, dma, facts = st
+        a, t = insts[i]
+        op, _, rest = t.partition(" ")
+        if op == "s_endpgm":
+            if dma:
+                bad.add(a)
+            continue
+        f = dict(facts)
+        if t.startswith("global_load_lds"):
+            dma = True
+        elif op == "s_waitcnt" and re.search(r"vmcnt\(0\)", t):
+            dma = False
+        ops = [o.strip() for o in rest.split(",")]
+        taken = fall = True
+        if op in ("s_cbranch_vccz", "s_cbranch_vccnz") and "vcc" in f:
+            zero = f["vcc"] == "z"
+            taken = zero if op == "s_cbranch_vccz" else not zero
+            fall = not taken
+        elif op == "s_mov_b64" and len(ops) == 2 and re.fullmatch(r"s\[\d+:\d+\]", ops[0]) and ops[1] in ("0", "-1"):
+            f[ops[0]] = ops[1]
+        elif op in ("s_andn2_b64", "s_and_b64") and len(ops) == 3 and ops[0] == "vcc" and ops[1] == "exec" and ops[2] in f:
+            nz = (f[ops[2]] == "0") if op == "s_andn2_b64" else (f[ops[2]] == "-1")
+            f["vcc"] = "nz" if nz else "z"
+        elif op.startswith(("s_", "v_cmp", "v_readfirstlane", "v_readlane")) and not op.startswith(("s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_barrier")):
+            # anything else that may write a tracked SGPR pair or vcc: forget it (destination = first operand; v_cmp writes vcc)
+            dst = ops[0] if ops else ""
+            wr = _sgprs(dst)
+            for k in list(f):
+                if k == "vcc":
+                    if "vcc" in dst or op.startswith("v_cmp"):
+                        del f[k]
+                elif _sgprs(k) & wr:
+                    del f[k]
+        nf = frozenset(f.items())
+        if op == "s_branch":
+            tgt = branch_target(a, rest)
+            if tgt is not None:
+                work.append((tgt, dma, nf))
+            continue
+        if op.startswith("s_cbranch"):
+            tgt = branch_target(a, rest)
+            if tgt is not None and taken:
+                work.append((tgt, dma, nf))
+            if fall and i + 1 < n:
+                work.append((i + 1, dma, nf))
+            continue
+        if i + 1 < n:
+            work.append((i + 1, dma, nf))
+    return [f"s_endpgm at {a:#x} reachable with an LDS-DMA (global_load_lds) possibly in flight: no s_waitcnt vmcnt(0) on some path"
+            for a in sorted(bad)]
+
+
 def lint_text(text):
     report = {}
+    with_addr = split_kernels_addr(text)
     for name, insts in split_kernels(text).items():
         n_mfma, n_pk, findings = lint_kernel(name, insts)
-        report[name] = {"mfma": n_mfma, "pk_f32": n_pk, "findings": findings}
+        n_dma = sum(1 for i in insts if i.startswith("global_load_lds"))
+        findings = findings + lint_dma_drain(with_addr.get(name, []))
+        report[name] = {"mfma": n_mfma, "pk_f32": n_pk, "lds_dma": n_dma, "findings": findings}
     return report
 
 

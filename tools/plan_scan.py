@@ -12,7 +12,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["TFFT_DEBUG_VARIANTS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import debuglib  # noqa: E402,F401  (libtfft_debug.so: timing-only variants and env knobs)
 import torch
 import __graft_entry__ as g
 

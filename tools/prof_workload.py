@@ -16,7 +16,9 @@ sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as g
 
-g.build()
+# runs under rocprofv3: load the prebuilt library only, never start a compiler here (tools/profile_pmc.sh builds first)
+if not g.is_current():
+    raise SystemExit("libtfft.so is missing or stale: run `python3 -c 'import __graft_entry__ as g; g.build()'` first")
 import tensor_fft_amd as tf
 
 name = sys.argv[1]

@@ -9,6 +9,9 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
+# build BEFORE the first profiler line: under rocprofv3 (with --pmc its preloaded library has initialised the GPU) nothing may
+# start hipcc / make any more (that would be a wrapper hop after GPU initialisation, which this pool forbids)
+python3 -c 'import __graft_entry__ as g; g.build()'
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$TAG -o t -- python3 tools/prof_workload.py $WL 10 > $OUT/trace_$TAG.log 2>&1
 echo "trace $TAG done"
 i=0

@@ -57,6 +57,7 @@ def main():
             m = (1 << lg) * inner * int(rng.choice([1, 2, 8]))
             kw["fourstep_n"] = m
             kw["fourstep_col0"] = int(rng.integers(0, m // (1 << lg) - inner + 1)) // 8 * 8
+            kw["scale"] = str(rng.choice(["sequential", "sequential", "none", "once"]))
         elif kind == "scale":
             lg = int(rng.integers(1, 22))
             kw["scale"] = str(rng.choice(["none", "once"]))
