@@ -296,3 +296,247 @@ std::optional<std::string> ComputeFFT(const Plan<Integer>& fft_plan, const DataB
   (void)hipDeviceSynchronize();
   return tfft_detail::peek();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-GPU. The reference's counterpart is dead code (ComputeFFTMultiGPU / ComputeFFTsMultiGPU,
+// src/base/ComputeFFT.h:295-557; DataHandlerMultiGPU / DataBatchHandlerMultiGPU, src/base/DataHandler.h:168-403) that ran
+// one independent transform (or batch) per device. Same names and call sequence here, MI355X meaning:
+//
+//   DataBatchHandlerMultiGPU + ComputeFFTsMultiGPU   ONE batch sharded contiguously over the devices (BASELINE configs[4a]):
+//                                                    independent transforms, no collective, one enqueue per device
+//   DataHandlerMultiGPU + ComputeFFTMultiGPU         ONE transform of fft_length spread over the devices (configs[4b]):
+//                                                    four-step FFT with a single RCCL exchange over xGMI (tfft_dist_*)
+//
+// Both drive all devices from the calling thread (the shape of the reference's loops over cudaSetDevice); a program with
+// one process per GPU uses tfft_dist_* / tfft_exec directly (tensor-fft_amd/distributed.py, bench.py).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename Integer>
+class DataBatchHandlerMultiGPU {
+ public:
+  // amount_of_ffts = the WHOLE batch; device i takes transforms [first_[i], first_[i] + count_[i])
+  DataBatchHandlerMultiGPU(const Integer fft_length, const int amount_of_ffts, std::vector<int> device_ids)
+      : fft_length_(fft_length), amount_of_ffts_(amount_of_ffts), device_ids_(std::move(device_ids)) {
+    const int nd = static_cast<int>(device_ids_.size());
+    dptr_data_.assign(nd, nullptr);
+    for (int i = 0; i < nd; ++i) {
+      const int per = amount_of_ffts_ / nd, extra = amount_of_ffts_ % nd;
+      first_.push_back(i * per + std::min(i, extra));
+      count_.push_back(per + (i < extra ? 1 : 0));
+      (void)hipSetDevice(device_ids_[i]);
+      if (count_[i] && hipMalloc(reinterpret_cast<void**>(&dptr_data_[i]),
+                                 static_cast<size_t>(count_[i]) * 4 * sizeof(__half) * fft_length_) != hipSuccess)
+        std::cout << hipGetErrorString(hipPeekAtLastError()) << std::endl;
+    }
+  }
+  DataBatchHandlerMultiGPU(const DataBatchHandlerMultiGPU&) = delete;
+  DataBatchHandlerMultiGPU& operator=(const DataBatchHandlerMultiGPU&) = delete;
+  ~DataBatchHandlerMultiGPU() {
+    for (size_t i = 0; i < device_ids_.size(); ++i) {
+      (void)hipSetDevice(device_ids_[i]);
+      (void)hipFree(dptr_data_[i]);
+    }
+  }
+
+  __half* input(int i) const { return dptr_data_[i]; }
+  __half* results(int i) const { return dptr_data_[i] + static_cast<size_t>(count_[i]) * 2 * fft_length_; }
+
+  std::optional<std::string> PeakAtLastError() {
+    for (int d : device_ids_) {
+      (void)hipSetDevice(d);
+      if (auto e = tfft_detail::peek()) return e;
+    }
+    return std::nullopt;
+  }
+
+  // data: the whole batch, [fft_i RE | fft_i IM] blocks in order (DataBatchHandler's layout)
+  std::optional<std::string> CopyDataHostToDevice(__half* data) {
+    for (size_t i = 0; i < device_ids_.size(); ++i) {
+      if (!count_[i]) continue;
+      (void)hipSetDevice(device_ids_[i]);
+      if (auto e = tfft_detail::hip_status(hipMemcpy(input(static_cast<int>(i)), data + static_cast<size_t>(first_[i]) * 2 * fft_length_,
+                                                     static_cast<size_t>(count_[i]) * 2 * fft_length_ * sizeof(__half), hipMemcpyHostToDevice)))
+        return e;
+    }
+    return std::nullopt;
+  }
+
+  std::optional<std::string> CopyResultsDeviceToHost(__half* data, bool results_in_results) {
+    for (size_t i = 0; i < device_ids_.size(); ++i) {
+      if (!count_[i]) continue;
+      (void)hipSetDevice(device_ids_[i]);
+      const __half* src = results_in_results ? results(static_cast<int>(i)) : input(static_cast<int>(i));
+      if (auto e = tfft_detail::hip_status(hipMemcpy(data + static_cast<size_t>(first_[i]) * 2 * fft_length_, src,
+                                                     static_cast<size_t>(count_[i]) * 2 * fft_length_ * sizeof(__half), hipMemcpyDeviceToHost)))
+        return e;
+    }
+    return std::nullopt;
+  }
+
+  Integer fft_length_;
+  int amount_of_ffts_;
+  std::vector<int> device_ids_;
+  std::vector<int> first_, count_;
+  std::vector<__half*> dptr_data_;
+};
+
+// The whole batch: every device gets one enqueue for its slice, then all devices are synchronised (the reference's batch
+// overload ends with a device synchronise too).
+template <typename Integer>
+std::optional<std::string> ComputeFFTsMultiGPU(const Plan<Integer>& fft_plan, const DataBatchHandlerMultiGPU<Integer>& data) {
+  for (size_t i = 0; i < data.device_ids_.size(); ++i) {
+    if (!data.count_[i]) continue;
+    if (hipSetDevice(data.device_ids_[i]) != hipSuccess) return std::string("hipSetDevice failed");
+    std::string err;
+    tfft_plan* p = tfft_detail::exec_plan(static_cast<uint64_t>(fft_plan.fft_length_), static_cast<uint64_t>(data.count_[i]),
+                                          fft_plan.tfft_variant_, &err);
+    if (!p) return err;
+    const int ii = static_cast<int>(i);
+    __half* out = fft_plan.results_in_results_ ? data.results(ii) : data.input(ii);
+    if (tfft_exec(p, data.input(ii), data.input(ii) + fft_plan.fft_length_, out, out + fft_plan.fft_length_, nullptr) != TFFT_OK)
+      return std::string(tfft_last_error());
+  }
+  for (int d : data.device_ids_) {
+    (void)hipSetDevice(d);
+    (void)hipDeviceSynchronize();
+    if (auto e = tfft_detail::peek()) return e;
+  }
+  return std::nullopt;
+}
+
+// ONE transform of fft_length over the devices. Device p holds the "columns" slice x[n1 N2 + p C + c] as an [N1][C] matrix per
+// plane and ends up with X[k1 + N1 k2], k1 in its block of K rows, as a [K][N2] matrix per plane (tfft.h, tfft_dist_*).
+// The host copies below scatter a natural-order signal / gather a natural-order spectrum.
+template <typename Integer>
+class DataHandlerMultiGPU {
+ public:
+  // self_via_comm: route the own chunk through RCCL too (lets a box with one GPU run the collective path; tests)
+  DataHandlerMultiGPU(const Integer fft_length, std::vector<int> device_ids, bool self_via_comm = false)
+      : fft_length_(fft_length), device_ids_(std::move(device_ids)) {
+    const int nd = static_cast<int>(device_ids_.size());
+    plans_.assign(nd, nullptr);
+    comms_.assign(nd, nullptr);
+    dptr_data_.assign(nd, nullptr);
+    if (nd > 1 || self_via_comm) {
+      if (tfft_dist_comm_create_all(nd, device_ids_.data(), comms_.data()) != TFFT_OK) {
+        error_ = tfft_last_error();
+        std::cout << error_ << std::endl;
+        return;
+      }
+    }
+    for (int i = 0; i < nd; ++i) {
+      if (tfft_dist_plan_create(static_cast<uint64_t>(fft_length_), nd, i, device_ids_[i], comms_[i],
+                                self_via_comm ? TFFT_DIST_SELF_VIA_COMM : 0, &plans_[i]) != TFFT_OK) {
+        error_ = tfft_last_error();
+        std::cout << error_ << std::endl;
+        return;
+      }
+      (void)hipSetDevice(device_ids_[i]);
+      if (hipMalloc(reinterpret_cast<void**>(&dptr_data_[i]), 4 * sizeof(__half) * local()) != hipSuccess)
+        std::cout << hipGetErrorString(hipPeekAtLastError()) << std::endl;
+    }
+    (void)tfft_dist_plan_geometry(plans_[0], &geometry_);
+  }
+  DataHandlerMultiGPU(const DataHandlerMultiGPU&) = delete;
+  DataHandlerMultiGPU& operator=(const DataHandlerMultiGPU&) = delete;
+  ~DataHandlerMultiGPU() {
+    for (size_t i = 0; i < device_ids_.size(); ++i) {
+      (void)hipSetDevice(device_ids_[i]);
+      (void)hipDeviceSynchronize();
+      tfft_dist_plan_destroy(plans_[i]);
+      (void)hipFree(dptr_data_[i]);
+    }
+    for (void* c : comms_) (void)tfft_dist_comm_destroy(c);
+  }
+
+  size_t local() const { return static_cast<size_t>(fft_length_) / device_ids_.size(); }   // samples per device
+  __half* input_RE(int i) const { return dptr_data_[i]; }
+  __half* input_IM(int i) const { return dptr_data_[i] + local(); }
+  __half* results_RE(int i) const { return dptr_data_[i] + 2 * local(); }
+  __half* results_IM(int i) const { return dptr_data_[i] + 3 * local(); }
+
+  std::optional<std::string> PeakAtLastError() {
+    if (!error_.empty()) return error_;
+    for (int d : device_ids_) {
+      (void)hipSetDevice(d);
+      if (auto e = tfft_detail::peek()) return e;
+    }
+    return std::nullopt;
+  }
+
+  // data = [RE: N halves | IM: N halves] in natural order; device p receives columns [p C, (p + 1) C) of the [N1][N2] view
+  std::optional<std::string> CopyDataHostToDevice(__half* data) {
+    if (!error_.empty()) return error_;
+    const size_t n1 = geometry_.n1, n2 = geometry_.n2, c = geometry_.cols;
+    for (size_t i = 0; i < device_ids_.size(); ++i) {
+      (void)hipSetDevice(device_ids_[i]);
+      for (int plane = 0; plane < 2; ++plane) {
+        __half* dst = plane ? input_IM(static_cast<int>(i)) : input_RE(static_cast<int>(i));
+        const __half* src = data + static_cast<size_t>(plane) * fft_length_ + i * c;
+        if (auto e = tfft_detail::hip_status(hipMemcpy2D(dst, c * sizeof(__half), src, n2 * sizeof(__half), c * sizeof(__half), n1,
+                                                         hipMemcpyHostToDevice)))
+          return e;
+      }
+    }
+    return std::nullopt;
+  }
+
+  // data = [RE | IM] of X in natural order (the devices' [K][N2] blocks hold X[k1 + N1 k2]; the transposition to
+  // natural order is done here on the host: a convenience path, the device-resident result stays in its blocks)
+  std::optional<std::string> CopyResultsDeviceToHost(__half* data) {
+    if (!error_.empty()) return error_;
+    const size_t n1 = geometry_.n1, n2 = geometry_.n2, k = geometry_.rows;
+    std::vector<__half> stage(local());
+    for (size_t i = 0; i < device_ids_.size(); ++i) {
+      (void)hipSetDevice(device_ids_[i]);
+      for (int plane = 0; plane < 2; ++plane) {
+        const __half* src = plane ? results_IM(static_cast<int>(i)) : results_RE(static_cast<int>(i));
+        if (auto e = tfft_detail::hip_status(hipMemcpy(stage.data(), src, local() * sizeof(__half), hipMemcpyDeviceToHost))) return e;
+        __half* dst = data + static_cast<size_t>(plane) * fft_length_;
+        for (size_t kk = 0; kk < k; ++kk) {
+          const size_t k1 = i * k + kk;
+          for (size_t k2 = 0; k2 < n2; ++k2) dst[k1 + n1 * k2] = stage[kk * n2 + k2];
+        }
+      }
+    }
+    return std::nullopt;
+  }
+
+  Integer fft_length_;
+  std::vector<int> device_ids_;
+  std::vector<tfft_dist_plan*> plans_;
+  std::vector<void*> comms_;
+  std::vector<__half*> dptr_data_;
+  tfft_dist_geometry geometry_{};
+  std::string error_;
+};
+
+// Column pass on every device, ONE grouped exchange (all devices' sends and receives inside one RCCL group), row transforms
+// on every device; asynchronous like the single-transform ComputeFFT (default stream of each device, no synchronise).
+template <typename Integer>
+std::optional<std::string> ComputeFFTMultiGPU(Plan<Integer>& fft_plan, DataHandlerMultiGPU<Integer>& data) {
+  if (fft_plan.fft_length_ != data.fft_length_) return std::string("Error! Plan and data handler have different fft lengths.");
+  if (!data.error_.empty()) return data.error_;
+  const int nd = static_cast<int>(data.device_ids_.size());
+  for (int i = 0; i < nd; ++i) {
+    if (hipSetDevice(data.device_ids_[i]) != hipSuccess) return std::string("hipSetDevice failed");
+    if (tfft_dist_exec_pre(data.plans_[i], data.input_RE(i), data.input_IM(i), nullptr) != TFFT_OK) return std::string(tfft_last_error());
+  }
+  if (data.comms_[0]) {
+    if (tfft_dist_group_start() != TFFT_OK) return std::string(tfft_last_error());
+    for (int i = 0; i < nd; ++i) {
+      (void)hipSetDevice(data.device_ids_[i]);
+      if (tfft_dist_exec_exchange(data.plans_[i], nullptr) != TFFT_OK) {
+        const std::string keep = tfft_last_error();
+        (void)tfft_dist_group_end();
+        return keep;
+      }
+    }
+    if (tfft_dist_group_end() != TFFT_OK) return std::string(tfft_last_error());
+  }
+  for (int i = 0; i < nd; ++i) {
+    (void)hipSetDevice(data.device_ids_[i]);
+    if (tfft_dist_exec_post(data.plans_[i], data.results_RE(i), data.results_IM(i), nullptr) != TFFT_OK)
+      return std::string(tfft_last_error());
+  }
+  return std::nullopt;
+}

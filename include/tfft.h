@@ -40,7 +40,8 @@ enum {
   TFFT_ERR_ARG = 5,        /* null / misaligned pointer, bad stride, bad batch */
   TFFT_ERR_DEVICE = 6,     /* not a gfx950 / wave64 / 160 KiB-LDS device (Plan.h:257-296) */
   TFFT_ERR_HIP = 7,        /* a HIP runtime call failed; text in tfft_last_error() */
-  TFFT_ERR_WORKSPACE = 8   /* workspace needed but missing / too small */
+  TFFT_ERR_WORKSPACE = 8,  /* workspace needed but missing / too small */
+  TFFT_ERR_COMM = 9        /* RCCL: library not loadable, a collective call failed, or no communicator where one is needed */
 };
 
 /* BaseFFTMode of the reference (src/base/Plan.h:14). */
@@ -223,6 +224,70 @@ int tfft_plan2d_exec_inverse(const tfft_plan2d* plan, const void* in_re, const v
  * src/base/ComputeFFT.h:295-557 is commented out). Not in place. */
 int tfft_permute_twiddle(const void* in_re, const void* in_im, void* out_re, void* out_im, uint64_t a,
                          uint64_t b, uint64_t c, uint64_t n_tw, uint64_t e0, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * One transform spread over the GPUs of a node (BASELINE configs[4b]: single N = 2^26 with ONE all-to-all over xGMI).
+ * The reference has no counterpart: its multi-GPU code is commented out and ran one independent transform per device
+ * (ComputeFFTMultiGPU, src/base/ComputeFFT.h:295-411; DataHandlerMultiGPU, src/base/DataHandler.h:168-403). Shape here: one
+ * plan per rank (= per GPU; ranks may be processes, or the devices of one process), four-step FFT with N = N1 N2:
+ *
+ *   input  ("columns"):    rank p holds x[n1 N2 + p C + c], n1 < N1, c < C = N2 / P, as an [N1][C] matrix per plane
+ *   tfft_dist_exec_pre       one radix-N1 column pass with the four-step twiddle fused in -> the plan's send buffers
+ *   tfft_dist_exec_exchange  chunk q (K C halves per plane, K = N1 / P) of the send buffers -> rank q's receive buffers:
+ *                            one ncclGroupStart / ncclSend + ncclRecv per peer and plane / ncclGroupEnd on `stream`
+ *   tfft_dist_exec_post      N2-point row transforms straight out of the receive buffers (no re-order pass where the
+ *                            row transform starts with a radix-256 / 512 column pass, see tfft_dist_geometry.reorder)
+ *   output ("transposed"): rank q holds X[k1 + N1 k2], k1 = q K + k, as a [K][N2] matrix per plane
+ *
+ * tfft_dist_exec = the three in order on one stream, so the kernels and the collective are ordered by that stream. A
+ * process that drives several devices itself runs the phases device by device and brackets the exchange calls of all its
+ * devices with tfft_dist_group_start / _end (RCCL's rule for one thread and several communicators). Every buffer is allocated at
+ * plan creation; the exec calls only enqueue. Result = DFT(x) / N like tfft_exec. RCCL is bound with dlopen at the first
+ * tfft_dist_* call that needs it; plans for one rank (world = 1) or with comm = NULL never load it. */
+typedef struct tfft_dist_plan tfft_dist_plan;
+
+typedef struct tfft_dist_geometry {
+  uint64_t n, n1, n2;  /* N = N1 N2 */
+  uint64_t cols;       /* C = N2 / world: columns per rank in the column pass */
+  uint64_t rows;       /* K = N1 / world: rows per rank in the row pass */
+  uint64_t chunk;      /* K C: halves per plane that go to each peer */
+  int world, rank;
+  int fused;           /* 1: the four-step twiddle rides in the column pass's epilogue (always, today) */
+  int reorder;         /* 1: a re-order pass [p'][k][c] -> [k][p' C + c] runs in front of the row transforms; 0: they read the segments in place */
+  int local_passes;    /* passes over this rank's N / world samples per transform */
+} tfft_dist_geometry;
+
+/* Host only: the split tfft_dist_plan_create would choose (TFFT_ERR_ARG when N < 256 * 64 * world). */
+int tfft_dist_geometry_query(uint64_t n, int world, int rank, tfft_dist_geometry* out);
+
+/* RCCL plumbing for callers that do not bind RCCL themselves. id: TFFT_DIST_ID_BYTES bytes (an ncclUniqueId) made on one rank,
+ * carried to the others by the caller (file, socket, MPI, torch.distributed ...). *comm is an ncclComm_t. */
+#define TFFT_DIST_ID_BYTES 128
+int tfft_dist_unique_id(void* id128);
+int tfft_dist_comm_create(int world, int rank, const void* id128, int device_id, void** comm);
+int tfft_dist_comm_create_all(int ndev, const int* devices, void** comms);   /* one process, ndev devices (ncclCommInitAll) */
+int tfft_dist_comm_destroy(void* comm);
+int tfft_dist_group_start(void);
+int tfft_dist_group_end(void);
+
+/* comm: this rank's ncclComm_t (the caller's own or from tfft_dist_comm_create), or NULL: then tfft_dist_exec_exchange is
+ * unavailable and the caller moves the chunks itself between _pre and _post (tfft_dist_plan_buffers; how the tests run
+ * several ranks on one GPU, and how another transport than RCCL would plug in). */
+/* flags: TFFT_DIST_SELF_VIA_COMM = the rank's own chunk travels through ncclSend / ncclRecv (to itself, inside the same group)
+ * instead of a device-to-device copy. No use in production; it lets a box with ONE GPU run the RCCL path of the exchange
+ * (world = 1: kernel -> collective -> kernel on one stream). */
+enum { TFFT_DIST_SELF_VIA_COMM = 1 };
+int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* comm, int flags, tfft_dist_plan** out);
+void tfft_dist_plan_destroy(tfft_dist_plan* plan);
+int tfft_dist_plan_geometry(const tfft_dist_plan* plan, tfft_dist_geometry* out);
+/* The exchange buffers (N / world halves each; chunk q at + q * chunk). set_buffers replaces them by caller-owned device
+ * memory (16-byte aligned), e.g. tensors a framework's own collective can send. */
+int tfft_dist_plan_buffers(const tfft_dist_plan* plan, void** send_re, void** send_im, void** recv_re, void** recv_im);
+int tfft_dist_plan_set_buffers(tfft_dist_plan* plan, void* send_re, void* send_im, void* recv_re, void* recv_im);
+int tfft_dist_exec_pre(const tfft_dist_plan* plan, const void* in_re, const void* in_im, void* stream);
+int tfft_dist_exec_exchange(const tfft_dist_plan* plan, void* stream);
+int tfft_dist_exec_post(const tfft_dist_plan* plan, void* out_re, void* out_im, void* stream);
+int tfft_dist_exec(const tfft_dist_plan* plan, const void* in_re, const void* in_im, void* out_re, void* out_im, void* stream);
 
 /* Layout adapters either side of the path: interleaved (re, im) half2 samples, as cuFFT / hipFFT callers and the
  * reference's comparison code hold them (src/testing/AccuracyCalculator.h:35-48, TestingDataCreation.h half2

@@ -8,7 +8,7 @@ _LIB_NAME = "libtfft.so"
 TFFT_OK = 0
 ERR_NAMES = {
     1: "TFFT_ERR_NOT_POW2", 2: "TFFT_ERR_TOO_SMALL", 3: "TFFT_ERR_MODE", 4: "TFFT_ERR_GEOMETRY",
-    5: "TFFT_ERR_ARG", 6: "TFFT_ERR_DEVICE", 7: "TFFT_ERR_HIP", 8: "TFFT_ERR_WORKSPACE",
+    5: "TFFT_ERR_ARG", 6: "TFFT_ERR_DEVICE", 7: "TFFT_ERR_HIP", 8: "TFFT_ERR_WORKSPACE", 9: "TFFT_ERR_COMM",
 }
 
 # every symbol include/tfft.h declares (tests check that the library exports them all)
@@ -20,6 +20,10 @@ SYMBOLS = [
     "tfft_plan2d_create", "tfft_plan2d_destroy", "tfft_plan2d_num_launches", "tfft_plan2d_workspace_bytes",
     "tfft_plan2d_set_workspace", "tfft_plan2d_exec", "tfft_plan2d_exec_inverse", "tfft_plan_describe",
     "tfft_variant_check", "tfft_plan_transposed_n2", "tfft_synth_uniform",
+    "tfft_dist_geometry_query", "tfft_dist_unique_id", "tfft_dist_comm_create", "tfft_dist_comm_create_all",
+    "tfft_dist_comm_destroy", "tfft_dist_group_start", "tfft_dist_group_end", "tfft_dist_plan_create",
+    "tfft_dist_plan_destroy", "tfft_dist_plan_geometry", "tfft_dist_plan_buffers", "tfft_dist_plan_set_buffers",
+    "tfft_dist_exec_pre", "tfft_dist_exec_exchange", "tfft_dist_exec_post", "tfft_dist_exec",
 ]
 
 SCALE_SEQUENTIAL, SCALE_NONE, SCALE_ONCE = 0, 1, 2           # tfft_plan_opts.scale
@@ -71,6 +75,18 @@ class PlanOpts(ctypes.Structure):
 
 def _debug_requested():
     return os.environ.get("TFFT_DEBUG_VARIANTS") == "1" and os.environ.get("TFFT_USE_DEBUG_LIB") == "1"
+
+
+class DistGeometry(ctypes.Structure):
+    """tfft_dist_geometry (include/tfft.h)."""
+    _fields_ = [
+        ("n", ctypes.c_uint64), ("n1", ctypes.c_uint64), ("n2", ctypes.c_uint64), ("cols", ctypes.c_uint64),
+        ("rows", ctypes.c_uint64), ("chunk", ctypes.c_uint64), ("world", ctypes.c_int), ("rank", ctypes.c_int),
+        ("fused", ctypes.c_int), ("reorder", ctypes.c_int), ("local_passes", ctypes.c_int),
+    ]
+
+
+DIST_ID_BYTES = 128
 
 
 def lib_path():
@@ -153,6 +169,39 @@ def load_library():
     L.tfft_plan_algorithmic_bytes.argtypes = [vp]
     L.tfft_plan_mfma_flops.restype = ctypes.c_double
     L.tfft_plan_mfma_flops.argtypes = [vp]
+    gp = ctypes.POINTER(DistGeometry)
+    L.tfft_dist_geometry_query.restype = ci
+    L.tfft_dist_geometry_query.argtypes = [u64, ci, ci, gp]
+    L.tfft_dist_unique_id.restype = ci
+    L.tfft_dist_unique_id.argtypes = [vp]
+    L.tfft_dist_comm_create.restype = ci
+    L.tfft_dist_comm_create.argtypes = [ci, ci, vp, ci, ctypes.POINTER(vp)]
+    L.tfft_dist_comm_create_all.restype = ci
+    L.tfft_dist_comm_create_all.argtypes = [ci, ctypes.POINTER(ci), ctypes.POINTER(vp)]
+    L.tfft_dist_comm_destroy.restype = ci
+    L.tfft_dist_comm_destroy.argtypes = [vp]
+    L.tfft_dist_group_start.restype = ci
+    L.tfft_dist_group_start.argtypes = []
+    L.tfft_dist_group_end.restype = ci
+    L.tfft_dist_group_end.argtypes = []
+    L.tfft_dist_plan_create.restype = ci
+    L.tfft_dist_plan_create.argtypes = [u64, ci, ci, ci, vp, ci, ctypes.POINTER(vp)]
+    L.tfft_dist_plan_destroy.restype = None
+    L.tfft_dist_plan_destroy.argtypes = [vp]
+    L.tfft_dist_plan_geometry.restype = ci
+    L.tfft_dist_plan_geometry.argtypes = [vp, gp]
+    L.tfft_dist_plan_buffers.restype = ci
+    L.tfft_dist_plan_buffers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.tfft_dist_plan_set_buffers.restype = ci
+    L.tfft_dist_plan_set_buffers.argtypes = [vp, vp, vp, vp, vp]
+    L.tfft_dist_exec_pre.restype = ci
+    L.tfft_dist_exec_pre.argtypes = [vp, vp, vp, vp]
+    L.tfft_dist_exec_exchange.restype = ci
+    L.tfft_dist_exec_exchange.argtypes = [vp, vp]
+    L.tfft_dist_exec_post.restype = ci
+    L.tfft_dist_exec_post.argtypes = [vp, vp, vp, vp]
+    L.tfft_dist_exec.restype = ci
+    L.tfft_dist_exec.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tfft_last_error.restype = ctypes.c_char_p
     L.tfft_last_error.argtypes = []
     L.tfft_version.restype = ctypes.c_char_p
@@ -342,6 +391,126 @@ class TfftPlan2D:
         if getattr(self, "_h", None):
             self._lib.tfft_plan2d_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+def dist_geometry(n, world, rank=0):
+    """tfft_dist_geometry_query: the four-step split of a transform distributed over `world` ranks. Host only."""
+    g = DistGeometry()
+    _check(load_library().tfft_dist_geometry_query(int(n), int(world), int(rank), ctypes.byref(g)))
+    return g
+
+
+def dist_unique_id():
+    """An ncclUniqueId (bytes) from tfft_dist_unique_id: make it on one rank, carry it to the others."""
+    buf = ctypes.create_string_buffer(DIST_ID_BYTES)
+    _check(load_library().tfft_dist_unique_id(buf))
+    return buf.raw
+
+
+class DistComm:
+    """Owning wrapper of an RCCL communicator created through the C ABI (tfft_dist_comm_create = ncclCommInitRank)."""
+
+    def __init__(self, world, rank, unique_id, device):
+        self._lib = load_library()
+        if len(unique_id) != DIST_ID_BYTES:
+            raise TfftError(5, "the unique id has to be 128 bytes")
+        self._h = ctypes.c_void_p()
+        _check(self._lib.tfft_dist_comm_create(int(world), int(rank), ctypes.c_char_p(unique_id), int(device), ctypes.byref(self._h)))
+        self.world, self.rank, self.device = int(world), int(rank), int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._h = None
+            self._lib.tfft_dist_comm_destroy(h)
+
+
+class DistPlan:
+    """Owning wrapper of tfft_dist_plan: this rank's share of ONE transform spread over `world` GPUs (include/tfft.h).
+    comm: a DistComm (the RCCL exchange then runs inside exec()) or None (pre() / post() only: the caller moves the
+    chunks between them, over whatever transport it has; `buffers=` hands in its own send / receive tensors)."""
+
+    def __init__(self, n, world, rank, device=0, comm=None, buffers=None, self_via_comm=False):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self._comm = comm
+        _check(self._lib.tfft_dist_plan_create(int(n), int(world), int(rank), int(device), comm.handle if comm else None,
+                                               1 if self_via_comm else 0, ctypes.byref(self._h)))
+        self.device = int(device)
+        g = DistGeometry()
+        _check(self._lib.tfft_dist_plan_geometry(self._h, ctypes.byref(g)))
+        self.geometry = g
+        self.local = int(g.n) // int(g.world)
+        self._bufs = None
+        if buffers is not None:
+            self.set_buffers(*buffers)
+
+    def set_buffers(self, send_re, send_im, recv_re, recv_im):
+        import torch
+
+        for t in (send_re, send_im, recv_re, recv_im):
+            if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.numel() >= self.local):
+                raise TfftError(5, "exchange buffers must be contiguous CUDA float16 tensors of N / world elements")
+        _check(self._lib.tfft_dist_plan_set_buffers(self._h, send_re.data_ptr(), send_im.data_ptr(), recv_re.data_ptr(),
+                                                    recv_im.data_ptr()))
+        self._bufs = (send_re, send_im, recv_re, recv_im)
+
+    def _stream(self, stream):
+        import torch
+
+        return torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+
+    def _planes(self, *tensors):
+        import torch
+
+        for t in tensors:
+            if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.numel() >= self.local
+                    and t.device.index == self.device):
+                raise TfftError(5, "planes must be contiguous CUDA float16 tensors of N / world elements on the plan's device")
+
+    def pre(self, in_re, in_im, stream=None):
+        import torch
+
+        self._planes(in_re, in_im)
+        with torch.cuda.device(self.device):
+            _check(self._lib.tfft_dist_exec_pre(self._h, in_re.data_ptr(), in_im.data_ptr(), self._stream(stream)))
+
+    def exchange(self, stream=None):
+        import torch
+
+        with torch.cuda.device(self.device):
+            _check(self._lib.tfft_dist_exec_exchange(self._h, self._stream(stream)))
+
+    def post(self, out_re, out_im, stream=None):
+        import torch
+
+        self._planes(out_re, out_im)
+        with torch.cuda.device(self.device):
+            _check(self._lib.tfft_dist_exec_post(self._h, out_re.data_ptr(), out_im.data_ptr(), self._stream(stream)))
+
+    def exec(self, in_re, in_im, out_re, out_im, stream=None):
+        import torch
+
+        self._planes(in_re, in_im, out_re, out_im)
+        with torch.cuda.device(self.device):
+            _check(self._lib.tfft_dist_exec(self._h, in_re.data_ptr(), in_im.data_ptr(), out_re.data_ptr(), out_im.data_ptr(),
+                                            self._stream(stream)))
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._h = None
+            self._lib.tfft_dist_plan_destroy(h)
 
     def __del__(self):
         try:

@@ -65,6 +65,12 @@ struct Args {
   uint32_t out_row_shift;
   uint32_t out_sub_shift;
   uint64_t out_sub_stride;
+  // Segmented input rows (workgroup-cooperative radix-256 / radix-512 forms): row i of the [radix][pitch] input matrix starts
+  // (i >> in_seg_shift) * in_seg_gap halves further on. The row transforms of a transform distributed over P GPUs read what
+  // the all-to-all delivered, P chunks [p'][k][c], in place: row k of the local [K][N2] matrix is P segments of C contiguous
+  // samples, K C apart (tfft_dist_*; no re-order pass). Off: shift 31, gap 0.
+  uint32_t in_seg_shift;
+  uint64_t in_seg_gap;
   const float2* tw_lo;
   const float2* tw_hi;
   const uint8_t* tables;            // k4096::build_tables blob
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
       const uint32_t r = sr * kRps + v / kCpr;
       const uint32_t chunk = v % kCpr;
       const uint64_t gcol = gc0 + 8 * chunk;
-      const uint64_t off = (r * a.pitch + (gcol & (a.pitch - 1))) * 2;
+      const uint64_t off = (r * a.pitch + static_cast<uint64_t>(r >> a.in_seg_shift) * a.in_seg_gap + (gcol & (a.pitch - 1))) * 2;
       const uint8_t* gr = reinterpret_cast<const uint8_t*>(a.in_re + (gcol >> pshift) * a.in_stride) + off;
       const uint8_t* gi = reinterpret_cast<const uint8_t*>(a.in_im + (gcol >> pshift) * a.in_stride) + off;
       const uint32_t d0 = img_off + 8192 * wave + 1024 * i, d1 = d0 + kPlane;
@@ -753,7 +759,8 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       const uint32_t v = (lane & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
       const uint32_t r = sr * kRps + v / kCpr;               // row of the sequence's 256-row image
       const uint32_t chunk = v % kCpr;
-      const uint64_t off = ((2 * r + seq) * a.pitch + mb + 8 * chunk) * 2;
+      const uint32_t row = 2 * r + seq;
+      const uint64_t off = (row * a.pitch + static_cast<uint64_t>(row >> a.in_seg_shift) * a.in_seg_gap + mb + 8 * chunk) * 2;
       raw_re[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off));
       raw_im[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off));
     }

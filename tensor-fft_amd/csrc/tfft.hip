@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -120,6 +121,10 @@ struct InternalOpts {
   uint64_t in_gstride = 0, out_gstride = 0;
   int once_log2 = -1;                    // TFFT_SCALE_ONCE: exponent of the single factor (default log2 n)
   bool rows2d = false;                   // tables for the fused 2D row pass (k4096r front end in front of the 4096 kernel)
+  // segmented input (row transforms of a distributed transform, dist.hpp): a transform's n samples arrive as n / in_seg_len
+  // segments of in_seg_len contiguous halves, in_seg_stride apart; in_batch_stride is then the distance between the first
+  // segments of consecutive transforms (< n). Only plans whose first pass is a cooperative radix-256 / 512 column pass.
+  uint64_t in_seg_len = 0, in_seg_stride = 0;
 };
 
 }  // namespace
@@ -140,6 +145,8 @@ struct tfft_plan {
   // then built for M instead of n
   uint64_t tw4_modulus = 0, tw4_col0 = 0;
   k4096::Addr in_map{}, out_map{};       // single-kernel plans: where transform b starts (plain or grouped)
+  uint32_t in_seg_shift = 31;            // segmented input rows of the first column pass (colfft::Args::in_seg_*; 31 / 0 = off)
+  uint64_t in_seg_gap = 0;
   // TFFT_ORDER_TRANSPOSED: strided radix-N1 column pass (with the four-step twiddle) into the workspace, then N1 * batch
   // contiguous N2-point transforms out of it; this plan then only owns the two sub-plans and the workspace
   tfft_plan* sub_col = nullptr;
@@ -502,6 +509,9 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   a.tw_scale = ps.tw_scale;
   a.comb_scale = ps.scale;
   a.tw4_col0 = p->tw4_col0;
+  const bool first_pass = &ps == &p->passes[0];
+  a.in_seg_shift = first_pass ? p->in_seg_shift : 31;
+  a.in_seg_gap = first_pass ? p->in_seg_gap : 0;
 #ifdef TFFT_DEBUG_KERNELS
   a.wg_times = nullptr;
   if (debug_variants_enabled())          // measurement hook of tools/exp_wg_end_times.py
@@ -973,7 +983,7 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   const uint64_t in_stride = (opts && opts->in_batch_stride) ? opts->in_batch_stride : 2 * nf;
   const uint64_t out_stride = (opts && opts->out_batch_stride) ? opts->out_batch_stride : 2 * nf;
   if (nf >= 8 && ((in_stride % 8) || (out_stride % 8))) return fail(TFFT_ERR_ARG, "batch strides must be multiples of 8 halves (16 bytes)");
-  if (in_stride < nf || out_stride < nf) return fail(TFFT_ERR_ARG, "batch stride smaller than the FFT length");
+  if ((in_stride < nf && !io.in_seg_len) || out_stride < nf) return fail(TFFT_ERR_ARG, "batch stride smaller than the FFT length");
   const int scale_mode = opts ? opts->scale : 0;
   if (scale_mode < TFFT_SCALE_SEQUENTIAL || scale_mode > TFFT_SCALE_ONCE) return fail(TFFT_ERR_ARG, "unknown tfft_plan_opts.scale");
   const int order = opts ? opts->output_order : 0;
@@ -1034,6 +1044,19 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   if (io.group_shift && !single_kernel(p)) return bail(fail(TFFT_ERR_ARG, "grouped addressing needs a single-kernel plan"));
   if (tw4 && !(p->passes.size() == 1 && p->passes[0].kind == PassKind::Col256))
     return bail(fail(TFFT_ERR_ARG, "fourstep_n: this (n, inner) does not plan as one column pass"));
+  if (io.in_seg_len) {
+    // the first pass must read rows of `pitch` halves through the cooperative radix-256 / radix-512 kernels, whole rows per
+    // segment; everything behind it works on the plan's own buffers
+    const Pass& f = p->passes[0];
+    const uint64_t pitch = f.kind == PassKind::Col256 ? n / static_cast<uint64_t>(f.radix) : 0;
+    const bool ok = inner == 1 && p->passes.size() >= 2 && p->preserve_input && f.kind == PassKind::Col256 &&
+                    (f.radix == 256 || f.radix == 512) && pitch % 128 == 0 && !(pvariant & (131072 | 4096 | 8192)) &&
+                    is_pow2(io.in_seg_len) && io.in_seg_len >= pitch && io.in_seg_len < n && io.in_seg_stride >= io.in_seg_len;
+    if (!ok) return bail(fail(TFFT_ERR_ARG, "segmented input: this length does not start with a cooperative radix-256 / radix-512 column pass "
+                                            "whose rows fit the segments"));
+    p->in_seg_shift = static_cast<uint32_t>(ilog2(io.in_seg_len / pitch));
+    p->in_seg_gap = io.in_seg_stride - io.in_seg_len;
+  }
   k4096::TableScale ts;
   double r_fa, r_fb, r_s;
   rc = apply_scale_mode(p, io, ts, r_fa, r_fb, r_s);
@@ -1493,3 +1516,5 @@ double tfft_plan_mfma_flops(const tfft_plan* p) {
 }
 
 }  // extern "C"
+
+#include "dist.hpp"

@@ -25,9 +25,17 @@ one fused re-order + twiddle kernel after the exchange.
 ``input_layout="natural"`` / ``output_layout="natural"`` (contiguous blocks of x / X per rank) cost one more
 exchange each, plus a pack / unpack re-order.
 
-The class holds only index logic and the collective; arithmetic is delegated to an *engine*
-(:class:`HipEngine` = libtfft.so on the GPU). Tests drive the same logic on CPU tensors over gloo with an
-engine of their own.
+With the GPU engine the fused form is a thin binding of the C ABI: ``tfft_dist_plan`` (include/tfft.h, csrc/dist.hpp) owns
+the column pass, the exchange (``ncclSend`` / ``ncclRecv`` in one group on the caller's stream, through a communicator this
+module creates with ``tfft_dist_comm_create`` from an id broadcast over the torch process group) and the row transforms,
+which read the received chunks IN PLACE (segmented rows, no re-order pass) wherever N2 >= 2^16. ``transport="torch"``
+keeps the exchange in Python (``batch_isend_irecv`` on the plan's send / receive tensors): what the tests use to run
+several ranks on one GPU, and the hook for any other transport. A C++ host uses the same entry points through
+``ComputeFFTMultiGPU`` of include/tensor_fft.hpp.
+
+The general form, the natural layouts and every non-GPU engine keep the index logic in this class, with the arithmetic
+delegated to an *engine* (:class:`HipEngine` = libtfft.so on the GPU). Tests drive that logic on CPU tensors over gloo with
+an engine of their own.
 """
 
 
@@ -99,9 +107,36 @@ class HipEngine:
         self.capi.permute_twiddle(re, im, o_re, o_im, a, b, c, n_tw, e0)
         return o_re, o_im
 
+    def dist_geometry(self, n, world, rank):
+        """The fused split the C ABI would choose (tfft_dist_geometry_query), or None when N is too small for it."""
+        try:
+            return self.capi.dist_geometry(n, world, rank)
+        except self.capi.TfftError:
+            return None
+
+    def dist_plan(self, n, world, rank, comm=None, self_via_comm=False):
+        """tfft_dist_plan for this rank with torch-owned exchange and output buffers. Returns (plan, send_re, send_im,
+        recv_re, recv_im, out_re, out_im); at world size 1 the receive buffers are the send buffers (unless the own chunk
+        is routed through the communicator, a test aid)."""
+        import torch
+
+        loc = n // world
+        dev = f"cuda:{self.device}"
+        mk = lambda: torch.empty(loc, dtype=torch.float16, device=dev)      # noqa: E731
+        send_re, send_im = mk(), mk()
+        recv_re, recv_im = (mk(), mk()) if (world > 1 or self_via_comm) else (send_re, send_im)
+        plan = self.capi.DistPlan(n, world, rank, self.device, comm=comm, buffers=(send_re, send_im, recv_re, recv_im),
+                                  self_via_comm=self_via_comm)
+        return plan, send_re, send_im, recv_re, recv_im, mk(), mk()
+
 
 class DistributedFFT1D:
-    def __init__(self, n, group=None, engine=None, input_layout="columns", output_layout="transposed", fused=None):
+    def __init__(self, n, group=None, engine=None, input_layout="columns", output_layout="transposed", fused=None,
+                 transport=None, self_via_comm=False):
+        """transport (GPU engine, fused form, more than one rank): "rccl" = the C ABI runs the exchange itself over a
+        communicator created through it (default when the process group's backend is nccl); "torch" = this class runs it
+        over torch.distributed on the plan's buffers (default otherwise). self_via_comm (with "rccl"): the own chunk goes
+        through ncclSend / ncclRecv too, so that a single GPU exercises the collective path (tests)."""
         import torch.distributed as dist
 
         if n & (n - 1) or n < 2:
@@ -141,6 +176,33 @@ class DistributedFFT1D:
             raise ValueError("unknown layout")
         self.input_layout, self.output_layout = input_layout, output_layout
         self._recv = {}
+        # fused form on the GPU engine: the core (column pass, exchange, row transforms) is one tfft_dist_plan
+        self._core = None
+        self.transport = None
+        if self.fused and hasattr(engine, "dist_plan"):
+            g = engine.dist_geometry(n, p, self.rank)
+            if g is not None:
+                assert (g.n1, g.n2, g.cols, g.rows) == (self.n1, self.n2, self.c, self.k), "C and Python geometry disagree"
+                if transport is None:
+                    transport = "rccl" if (p > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl") else "torch"
+                if transport not in ("rccl", "torch"):
+                    raise ValueError("transport must be 'rccl' or 'torch'")
+                self.transport = transport
+                self._via = bool(self_via_comm) and transport == "rccl"
+                self._comm = self._native_comm(engine) if (transport == "rccl" and (p > 1 or self._via)) else None
+                self._core = engine.dist_plan(n, p, self.rank, comm=self._comm, self_via_comm=self._via)
+                self.geometry = self._core[0].geometry
+
+    def _native_comm(self, engine):
+        """An RCCL communicator of this process group's ranks, created through the C ABI: rank 0 makes the id
+        (tfft_dist_unique_id = ncclGetUniqueId), the torch process group carries it, every rank joins
+        (tfft_dist_comm_create = ncclCommInitRank)."""
+        dist = self.dist
+        box = [engine.capi.dist_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
+            dist.broadcast_object_list(box, src=src, group=self.group)
+        return engine.capi.DistComm(self.world, self.rank, box[0], engine.device)
 
     # ---- layouts (what each rank holds, as index arrays into x / X; used by callers and tests)
     def input_indices(self, rank=None):
@@ -163,18 +225,19 @@ class DistributedFFT1D:
         k2 = np.arange(self.n2)[None, :]
         return (k1 + self.n1 * k2).reshape(-1)
 
-    def _exchange(self, re, im, role):
+    def _exchange(self, re, im, role, out=None):
         """All-to-all of both planes as ONE grouped operation: chunk q of each plane goes to rank q (one
         ncclGroupStart/End over RCCL: 2 (P - 1) sends and as many receives, every xGMI link busy at once). The receive
-        buffers are allocated once per role."""
+        buffers are `out` (the tfft_dist_plan's receive tensors) or allocated once per role."""
         p = self.world
         if p == 1:
             return re, im
-        key = (role, re.numel(), re.dtype, re.device)
-        out = self._recv.get(key)
         if out is None:
-            out = (re.new_empty(re.shape), im.new_empty(im.shape))
-            self._recv[key] = out
+            key = (role, re.numel(), re.dtype, re.device)
+            out = self._recv.get(key)
+            if out is None:
+                out = (re.new_empty(re.shape), im.new_empty(im.shape))
+                self._recv[key] = out
         o_re, o_im = out
         chunk = re.numel() // p
         dist = self.dist
@@ -206,7 +269,17 @@ class DistributedFFT1D:
             rows = self.n1 // p
             re, im = e.permute_twiddle(re, im, rows, p, self.c, role="pack_in")
             re, im = self._exchange(re, im, "in")
-        if self.fused:
+        if self._core is not None:
+            # the whole plain path in the C ABI: column pass with the four-step twiddle -> exchange -> row transforms
+            plan, send_re, send_im, recv_re, recv_im, out_re, out_im = self._core
+            if self.transport == "rccl" and (p > 1 or self._via):
+                plan.exec(re, im, out_re, out_im)
+            else:
+                plan.pre(re, im)
+                self._exchange(send_re, send_im, "main", out=(recv_re, recv_im))
+                plan.post(out_re, out_im)
+            re, im = out_re, out_im
+        elif self.fused:
             # 1 + 2. column transforms with the four-step twiddle in their epilogue
             re, im = e.fft_strided_fourstep(re, im, self.n1, self.c, self.n, self.rank * self.c)
             # 3. the one exchange of the plain path, 4. pure re-order (nothing to do on one rank)
@@ -218,8 +291,9 @@ class DistributedFFT1D:
             re, im = self._exchange(re, im, "main")
             # [p'][k][c] -> [k][p' C + c], twiddle w_N^((rank K + k)(p' C + c))
             re, im = e.permute_twiddle(re, im, p, self.k, self.c, self.n, self.rank * self.k, role="unpack")
-        # 5. row transforms
-        re, im = e.fft_rows(re, im, self.n2, self.k)
+        if self._core is None:
+            # 5. row transforms
+            re, im = e.fft_rows(re, im, self.n2, self.k)
         if self.output_layout == "natural" and p > 1:
             # rank holds [K][N2] = X[k1 + N1 k2]; natural block q wants k2 in its block (N2/P values), all k1:
             # [K][P][C] -> chunks [P][K][C], exchange -> [P'][K][C] = [k1][c] for its k2 block, then

@@ -141,7 +141,7 @@ def _rank_on_one_gpu(rank, world, port, n, in_layout, out_layout, fused, ret):
         from tensor_fft_amd.distributed import DistributedFFT1D, HipEngine
 
         class HostStagedExchange(DistributedFFT1D):
-            def _exchange(self, re, im, role):
+            def _exchange(self, re, im, role, out=None):
                 p = self.world
                 h_re, h_im = re.cpu(), im.cpu()
                 o_re, o_im = torch.empty_like(h_re), torch.empty_like(h_im)
@@ -157,6 +157,10 @@ def _rank_on_one_gpu(rank, world, port, n, in_layout, out_layout, fused, ret):
                             dist.P2POp(dist.irecv, o_re[sl], q), dist.P2POp(dist.irecv, o_im[sl], q)]
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
+                if out is not None:                    # the tfft_dist_plan's own receive tensors
+                    out[0].copy_(o_re)
+                    out[1].copy_(o_im)
+                    return out
                 return o_re.to(re.device), o_im.to(im.device)
 
         rng = np.random.default_rng(99)               # the same signal on every rank

@@ -469,10 +469,10 @@ def test_fourstep_twiddle_of_the_column_pass(tf, torch, n1, cols, m, col0, scale
     rng = np.random.default_rng(n1 + cols)
     re = rng.uniform(-1, 1, (batch, n1, cols)).astype(np.float16)
     im = rng.uniform(-1, 1, (batch, n1, cols)).astype(np.float16)
-    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
-    out = torch.full_like(dev, float("nan"))
     if scale == "none":
         re, im = (re / 64).astype(np.float16), (im / 64).astype(np.float16)        # unscaled stages: keep fp16 in range
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    out = torch.full_like(dev, float("nan"))
     plan = tf.TfftPlan(n1, batch, 0, inner=cols, fourstep_n=m, fourstep_col0=col0, scale=scale)
     assert plan.num_launches == 1
     plan.exec(dev, dev[n1 * cols:], out, out[n1 * cols:])
