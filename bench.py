@@ -2,6 +2,7 @@
 """bench.py — headline benchmark of the hot path: batched 1D N=4096 fp16 C2C FFT (BASELINE.json configs[1]).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W          (starts its N ranks itself, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -22,7 +23,9 @@ timed on this host's cores on a bounded sample of the same input: fp64 radix-2 F
 thread, plus the fp64 naive DFT/N at N=256 (BASELINE configs[0]) and at N=4096 on a 64-transform sub-batch.
 At 1 GPU `other_configs` carries short measurements of the other BASELINE configs (2^20 x 1024 natural and transposed
 order, 2D 4096^2 x 64, single 2^26) and neighbouring lengths, taken AFTER the timed region, each with an oracle check of
-a sampled transform / image; they do not enter `value`.
+a sampled transform / image; they do not enter `value`. With N > 1 GPUs `other_configs` carries BASELINE configs[4b] instead:
+ONE transform of N = 2^26 spread over the N GPUs with a single RCCL exchange (tfft_dist_exec), checked by Parseval over all ranks
+and four bins per rank against a direct fp64 DFT sum.
 """
 import argparse
 import json
@@ -281,6 +284,127 @@ def measured_traffic(kernel_name):
     return best
 
 
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n_ranks, script, script_args, nproc_visible=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as FRESH child processes under
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1), before this process has made any GPU call (a
+    process that has initialised the GPU must never be replaced or forked into ranks on this pool). The children inherit
+    stdout, so rank 0's JSON line is this command's output; the return code is non-zero if any rank failed.
+    nproc_visible: GPUs this box has (None: do not check; counting devices does not initialise the GPU)."""
+    import subprocess
+
+    if nproc_visible is not None and nproc_visible < n_ranks:
+        print(f"bench.py: --gpus {n_ranks} needs {n_ranks} GPUs, this box shows {nproc_visible}", file=sys.stderr, flush=True)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(script_args)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print(f"bench.py: the {n_ranks}-rank run failed (torch.distributed.run exit code {rc})", file=sys.stderr, flush=True)
+    return rc
+
+
+def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20):
+    """BASELINE configs[4b]: ONE transform of N = 2^26 spread over the `world` GPUs, four-step with a single RCCL exchange
+    (tfft_dist_exec: column pass -> ncclSend / ncclRecv group -> row transforms, all on one stream). Every rank calls this;
+    returns the report (identical on all ranks). Checked: Parseval over all ranks and four spectrum bins per rank against a
+    direct fp64 DFT sum of the (regenerated) input."""
+    import numpy as np
+    from tensor_fft_amd.distributed import DistributedFFT1D, HipEngine
+
+    n = 1 << 26
+    f = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="rccl" if world > 1 else None)
+    g = f.geometry
+    n1, n2, c, k = int(g.n1), int(g.n2), int(g.cols), int(g.rows)
+    # the whole signal on every rank (2 x 128 MiB; a pure function of the seed), this rank's columns sliced out of it
+    x = torch.empty(2 * n, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x, x[n:], n, 1, seed=SEED + 26)
+    in_re = x[:n].view(n1, n2)[:, rank * c:(rank + 1) * c].contiguous().view(-1)
+    in_im = x[n:].view(n1, n2)[:, rank * c:(rank + 1) * c].contiguous().view(-1)
+    token = torch.zeros(1, device="cuda")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.all_reduce(token)
+            torch.cuda.synchronize()
+
+    for _ in range(3):
+        re, im = f.forward(in_re, in_im)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        re, im = f.forward(in_re, in_im)
+    fence()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    # local work only (column pass + row transforms, no exchange) for the split of the time
+    plan = f._core[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    o_re, o_im = f._core[5], f._core[6]
+    fence()
+    e0.record()
+    for _ in range(reps):
+        plan.pre(in_re, in_im)
+        plan.post(o_re, o_im)
+    e1.record()
+    torch.cuda.synchronize()
+    local_ms = e0.elapsed_time(e1) / reps
+    re, im = f.forward(in_re, in_im)          # (the local-only runs above left stale receive buffers behind)
+    torch.cuda.synchronize()
+    t = torch.tensor([ms, local_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms, local_ms = float(t[0]), float(t[1])
+    # ---- checks
+    xs = x.double()
+    e_in = float((xs * xs).sum()) / n
+    e_out = (re.double() ** 2).sum() + (im.double() ** 2).sum()
+    if world > 1:
+        dist.all_reduce(e_out)
+    e_out = float(e_out)
+    if not abs(e_out - e_in) / e_in < 5e-3:
+        raise SystemExit(f"self-check failed: distributed N=2^26 Parseval {e_out} vs {e_in}")
+    tt = torch.arange(n, device="cuda", dtype=torch.float64)
+    worst = 0.0
+    for kk, k2 in ((0, 1), (k // 2, n2 // 3), (k - 1, n2 - 5), (1 % k, 4097)):
+        k1 = rank * k + kk
+        bin_ = k1 + n1 * k2                                         # X[k1 + N1 k2] lives at [kk][k2] of this rank
+        ph = -2.0 * np.pi * ((tt * bin_) % n) / n
+        cs, sn = torch.cos(ph), torch.sin(ph)
+        er = float((xs[:n] * cs - xs[n:] * sn).sum()) / n
+        ei = float((xs[:n] * sn + xs[n:] * cs).sum()) / n
+        worst = max(worst, abs(float(re[kk * n2 + k2]) - er), abs(float(im[kk * n2 + k2]) - ei))
+    w = torch.tensor([worst], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    worst = float(w[0])
+    rms = (e_in / n / 2) ** 0.5
+    if not worst < 8 * 2.0 ** -11 * max(rms, 2.0 ** -14):
+        raise SystemExit(f"self-check failed: distributed N=2^26 bins off by {worst:.3e} (spectrum rms {rms:.3e})")
+    sent = 2 * (world - 1) * int(g.chunk) * 2                       # bytes this rank sends (= receives): both planes
+    exch_ms = max(ms - local_ms, 1e-6)
+    return {
+        "ms": ms, "gsamples_per_s": n / ms / 1e6, "local_ms_without_exchange": local_ms,
+        "n1": n1, "n2": n2, "columns_per_rank": c, "rows_per_rank": k, "local_passes": int(g.local_passes),
+        "reorder_pass": bool(g.reorder), "transport": f.transport,
+        "bytes_sent_per_rank": sent, "exchange_GBps_per_rank": (sent / (exch_ms * 1e-3) / 1e9) if world > 1 else None,
+        "check": f"Parseval over all ranks + 4 bins per rank against a direct fp64 DFT sum on the device: max |delta| {worst:.2e} "
+                 f"(spectrum rms {rms:.2e})",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,12 +413,23 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="transforms per GPU (default: 65536 = BASELINE configs[1] at 1 GPU, 2^21 = the per-GPU share of "
                          "configs[4a] at N > 1 GPUs)")
+    ap.add_argument("--with-dist", action="store_true",
+                    help="also run the BASELINE configs[4b] entry (N = 2^26 through tfft_dist_*) when there is only one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra measurements of the other BASELINE configs (reported under 'other_configs')")
     args = ap.parse_args()
 
-    import torch
+    import torch                     # (importing torch and counting devices do not initialise the GPU)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher. Nothing has touched the GPU yet; build first so that the ranks
+        # only load the prebuilt library.
+        import __graft_entry__ as g
+
+        g.build()
+        sys.exit(self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:], nproc_visible=torch.cuda.device_count()))
+
     import __graft_entry__ as g
 
     g.build()
@@ -303,8 +438,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE={world})")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU (this box shows {torch.cuda.device_count()})")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:      # under torch.distributed.run even a single rank takes the RCCL path
@@ -442,10 +579,27 @@ def main():
             "mfma": {"tflops": mfma_tflops, "peak": MFMA_PEAK_TFLOPS, "frac": mfma_tflops / MFMA_PEAK_TFLOPS,
                      "flop_per_sample": 384},
         }
+        line["runtime"] = {
+            "world_size": dist.get_world_size() if dist is not None else 1,
+            "backend": dist.get_backend() if dist is not None else None,
+            "visible_gpus": torch.cuda.device_count(),
+            "device": torch.cuda.get_device_name(local_rank),
+            "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none",
+        }
         if world == 1 and not args.no_other_configs and batch == BATCH:
-            del x, y
+            x = y = None
             torch.cuda.empty_cache()
             line["other_configs"] = other_configs(torch, tf, orc, local_rank)
+    else:
+        line = None
+    if (world > 1 or args.with_dist) and not args.no_other_configs:
+        # BASELINE configs[4b]: every rank takes part (one exchange per transform); rank 0 reports
+        x = y = None
+        torch.cuda.empty_cache()
+        rep = dist_2pow26(torch, tf, dist, rank, world, local_rank)
+        if rank == 0:
+            line.setdefault("other_configs", {})["configs[4b]_n2^26_distributed"] = rep
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
