@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -41,6 +42,27 @@ int main(int argc, char** argv) {
     for (size_t b = 0; b < static_cast<size_t>(batch); ++b)
       std::copy(block.begin() + (b % distinct) * unit, block.begin() + (b % distinct + 1) * unit, host.begin() + b * unit);
     if (auto e = data.CopyDataHostToDevice(host.data())) { std::printf("%s\n", e->c_str()); return 1; }
+    // (c) the step either side of the path: the handlers' host <-> device copies of PAGEABLE memory through the pinned staging
+    // ring (tfft_copy_h2d / _d2h) next to one plain blocking hipMemcpy of the same bytes (what the reference's handlers do,
+    // src/base/DataHandler.h:116-153). Bound: PCIe Gen5 x16, ~63 GB/s per direction.
+    const double gb = static_cast<double>(host.size()) * sizeof(__half) * 1e-9;
+    auto secs = [](auto&& fn) {
+      const auto t0 = std::chrono::steady_clock::now();
+      fn();
+      (void)hipDeviceSynchronize();
+      return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    std::vector<__half> back(host.size());
+    double h2d_staged = 1e30, h2d_plain = 1e30, d2h_staged = 1e30, d2h_plain = 1e30;
+    for (int r = 0; r < 3; ++r) {
+      h2d_staged = std::min(h2d_staged, secs([&] { (void)data.CopyDataHostToDevice(host.data()); }));
+      h2d_plain = std::min(h2d_plain, secs([&] { (void)hipMemcpy(data.dptr_input_RE_[0], host.data(), host.size() * sizeof(__half), hipMemcpyHostToDevice); }));
+      d2h_staged = std::min(d2h_staged, secs([&] { (void)data.CopyResultsDeviceToHost(back.data(), false); }));
+      d2h_plain = std::min(d2h_plain, secs([&] { (void)hipMemcpy(back.data(), data.dptr_input_RE_[0], host.size() * sizeof(__half), hipMemcpyDeviceToHost); }));
+    }
+    if (std::memcmp(back.data(), host.data(), host.size() * sizeof(__half)) != 0) { std::printf("staged copy round trip differs\n"); return 1; }
+    std::printf("host <-> device, %.2f GB pageable: H2D staged %.1f GB/s (plain hipMemcpy %.1f), D2H staged %.1f GB/s (plain %.1f); "
+                "PCIe Gen5 x16 bound ~63 GB/s\n", gb, gb / h2d_staged, gb / h2d_plain, gb / d2h_staged, gb / d2h_plain);
   }
   const int smem = GetMaxNoOptInSharedMem(dev);
   for (int i = 0; i < warmup; ++i)

@@ -19,6 +19,8 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -54,6 +56,10 @@ struct Plan {
   // MI355X extension (not in the reference's struct): tuned kernel variant = sixth column of a tuner file written by
   // tools/tuner.py (tfft_plan_opts.variant); 0 = library default. CreatePlan(N, mode, ...) leaves it 0.
   int tfft_variant_ = 0;
+  // One entry per tuner-file line of this length (columns 6 - 8: variant, launch_iters, the batch the line was tuned at;
+  // batch 0 = no batch column). ComputeFFT picks the entry whose batch is nearest on a log scale to the batch it runs.
+  struct Tuned { long long batch; int variant; int launch_iters; };
+  std::vector<Tuned> tfft_tuned_;
 };
 
 template <typename Integer>
@@ -116,23 +122,29 @@ std::optional<Plan<Integer>> CreatePlan(const Integer fft_length, const std::str
     return std::nullopt;
   }
   std::string line;
+  std::optional<Plan<Integer>> plan;
   while (std::getline(file, line)) {
     std::istringstream ss(line);
     double len;
     int mode_num, bw, rw, r2;
     if (!(ss >> len >> mode_num >> bw >> rw >> r2)) continue;
     if (static_cast<Integer>(len) != fft_length) continue;
-    auto plan = CreatePlan(fft_length, mode_num == 256 ? Mode_256 : Mode_4096, bw, rw, r2);
-    int variant = 0;
-    if (plan && (ss >> variant)) {
-      if (tfft_variant_check(static_cast<uint64_t>(fft_length), 1, variant) != TFFT_OK) {
-        std::cout << "Error! Tuner file holds an unusable kernel variant for this fft length: " << tfft_last_error() << std::endl;
-        return std::nullopt;
-      }
-      plan->tfft_variant_ = variant;
+    if (!plan) {
+      plan = CreatePlan(fft_length, mode_num == 256 ? Mode_256 : Mode_4096, bw, rw, r2);
+      if (!plan) return std::nullopt;
     }
-    return plan;
+    int variant = 0;
+    if (!(ss >> variant)) break;          // a plain reference line: nothing more to read for this length
+    long long iters = 0, batch = 0;
+    if (ss >> iters) ss >> batch;
+    if (tfft_variant_check(static_cast<uint64_t>(fft_length), 1, variant) != TFFT_OK || iters < 0 || iters > 65535 || batch < 0) {
+      std::cout << "Error! Tuner file holds an unusable kernel variant for this fft length: " << tfft_last_error() << std::endl;
+      return std::nullopt;
+    }
+    if (plan->tfft_tuned_.empty()) plan->tfft_variant_ = variant;
+    plan->tfft_tuned_.push_back({batch, variant, static_cast<int>(iters)});
   }
+  if (plan) return plan;
   std::cout << "Error! Tuner file didnt contain requested fft length." << std::endl;
   return std::nullopt;
 }
@@ -152,33 +164,79 @@ inline std::optional<std::string> hip_status(hipError_t e) {
   return std::string(hipGetErrorString(e));
 }
 inline std::optional<std::string> peek() { return hip_status(hipPeekAtLastError()); }
+inline std::optional<std::string> staged(int rc) {
+  if (rc == TFFT_OK) return std::nullopt;
+  return std::string(tfft_last_error());
+}
 
 // One execution plan per (N, batch, device, variant), kept for the life of the process so that
 // ComputeFFT stays a pure launch, like the reference's. The cache is shared by all host threads (a tfft_plan is
 // immutable and thread-safe, tfft.h), hence the lock.
-inline tfft_plan* exec_plan(uint64_t n, uint64_t batch, int variant, std::string* err) {
-  static std::mutex lock;
-  static std::map<std::tuple<uint64_t, uint64_t, int, int>, tfft_plan*> cache;
+struct PlanCache {
+  std::mutex lock;
+  std::map<std::tuple<uint64_t, uint64_t, int, int, int>, tfft_plan*> plans;
+};
+inline PlanCache& plan_cache() {
+  static PlanCache c;
+  return c;
+}
+inline tfft_plan* exec_plan(uint64_t n, uint64_t batch, int variant, std::string* err, int launch_iters = 0) {
+  std::mutex& lock = plan_cache().lock;
+  auto& cache = plan_cache().plans;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) {
     *err = "hipGetDevice failed";
     return nullptr;
   }
-  const auto key = std::make_tuple(n, batch, dev, variant);
+  const auto key = std::make_tuple(n, batch, dev, variant, launch_iters);
   std::lock_guard<std::mutex> guard(lock);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   tfft_plan_opts opts{};
   opts.variant = variant;
+  opts.launch_iters = static_cast<uint32_t>(launch_iters);
   tfft_plan* p = nullptr;
   if (tfft_plan_create(n, batch, dev, &opts, &p) != TFFT_OK) {
     *err = tfft_last_error();
     return nullptr;
   }
+  // a multi-pass plan gets its workspace here, at creation: ComputeFFT itself never allocates
+  if (tfft_plan_prepare(p) != TFFT_OK) {
+    *err = tfft_last_error();
+    tfft_plan_destroy(p);
+    return nullptr;
+  }
   cache[key] = p;
   return p;
 }
+// (variant, launch_iters) of the tuner-file entry nearest to `batch` on a log scale; the plan's default without entries
+template <typename PlanT>
+inline std::pair<int, int> tuned_for_batch(const PlanT& plan, uint64_t batch) {
+  std::pair<int, int> best{plan.tfft_variant_, 0};
+  double best_d = -1;
+  for (const auto& t : plan.tfft_tuned_) {
+    const double d = t.batch > 0 ? std::fabs(std::log2(static_cast<double>(batch ? batch : 1)) - std::log2(static_cast<double>(t.batch))) : 1e9;
+    if (best_d < 0 || d < best_d) {
+      best = {t.variant, t.launch_iters};
+      best_d = d;
+    }
+  }
+  return best;
+}
 }  // namespace tfft_detail
+
+// Not in the reference (its plans own no device memory): destroys the execution plans ComputeFFT has cached, with their
+// constant tables and workspaces (a 2^26 plan holds 512 MiB). Call with no ComputeFFT in flight; later calls re-create.
+inline void ReleaseComputeFFTPlans() {
+  auto& c = tfft_detail::plan_cache();
+  std::lock_guard<std::mutex> guard(c.lock);
+  for (auto& kv : c.plans) {
+    (void)hipSetDevice(std::get<2>(kv.first));
+    (void)hipDeviceSynchronize();
+    tfft_plan_destroy(kv.second);
+  }
+  c.plans.clear();
+}
 
 // 4*N halves on the device: in_RE | in_IM | out_RE | out_IM.
 template <typename Integer>
@@ -198,14 +256,15 @@ class DataHandler {
 
   std::optional<std::string> PeakAtLastError() { return tfft_detail::peek(); }
 
+  // (pageable host memory travels through the library's pinned staging ring, tfft_copy_h2d / _d2h: chunked hipMemcpyAsync
+  // overlapped with the host-side copies; the reference: one blocking cudaMemcpy, DataHandler.h:45-70)
   std::optional<std::string> CopyDataHostToDevice(__half* data) {
-    return tfft_detail::hip_status(
-        hipMemcpy(dptr_input_RE_, data, 2 * fft_length_ * sizeof(__half), hipMemcpyHostToDevice));
+    return tfft_detail::staged(tfft_copy_h2d(dptr_input_RE_, data, 2 * static_cast<size_t>(fft_length_) * sizeof(__half)));
   }
 
   std::optional<std::string> CopyResultsDeviceToHost(__half* data, bool results_in_results) {
     const __half* src = results_in_results ? dptr_results_RE_ : dptr_input_RE_;
-    return tfft_detail::hip_status(hipMemcpy(data, src, 2 * fft_length_ * sizeof(__half), hipMemcpyDeviceToHost));
+    return tfft_detail::staged(tfft_copy_d2h(data, src, 2 * static_cast<size_t>(fft_length_) * sizeof(__half)));
   }
 
   Integer fft_length_;
@@ -240,20 +299,15 @@ class DataBatchHandler {
 
   std::optional<std::string> PeakAtLastError() { return tfft_detail::peek(); }
 
+  // pinned, chunked, overlapped (tfft_copy_h2d / _d2h); the reference: one blocking cudaMemcpy, DataHandler.h:116-153
   std::optional<std::string> CopyDataHostToDevice(__half* data) {
-    auto r = tfft_detail::hip_status(hipMemcpy(dptr_input_RE_[0], data,
-                                               static_cast<size_t>(amount_of_ffts_) * 2 * fft_length_ * sizeof(__half),
-                                               hipMemcpyHostToDevice));
-    if (r) return r;
-    (void)hipDeviceSynchronize();
-    return std::nullopt;
+    return tfft_detail::staged(tfft_copy_h2d(dptr_input_RE_[0], data,
+                                             static_cast<size_t>(amount_of_ffts_) * 2 * fft_length_ * sizeof(__half)));
   }
 
   std::optional<std::string> CopyResultsDeviceToHost(__half* data, bool results_in_results) {
     const __half* src = results_in_results ? dptr_results_RE_[0] : dptr_input_RE_[0];
-    return tfft_detail::hip_status(hipMemcpy(data, src,
-                                             static_cast<size_t>(amount_of_ffts_) * 2 * fft_length_ * sizeof(__half),
-                                             hipMemcpyDeviceToHost));
+    return tfft_detail::staged(tfft_copy_d2h(data, src, static_cast<size_t>(amount_of_ffts_) * 2 * fft_length_ * sizeof(__half)));
   }
 
   Integer fft_length_;
@@ -271,7 +325,8 @@ template <typename Integer>
 std::optional<std::string> ComputeFFT(Plan<Integer>& fft_plan, const DataHandler<Integer>& data,
                                       const int /*max_no_optin_shared_mem*/ = 32768) {
   std::string err;
-  tfft_plan* p = tfft_detail::exec_plan(static_cast<uint64_t>(fft_plan.fft_length_), 1, fft_plan.tfft_variant_, &err);
+  const auto tuned = tfft_detail::tuned_for_batch(fft_plan, 1);
+  tfft_plan* p = tfft_detail::exec_plan(static_cast<uint64_t>(fft_plan.fft_length_), 1, tuned.first, &err, tuned.second);
   if (!p) return err;
   __half* out_re = fft_plan.results_in_results_ ? data.dptr_results_RE_ : data.dptr_input_RE_;
   __half* out_im = fft_plan.results_in_results_ ? data.dptr_results_IM_ : data.dptr_input_IM_;
@@ -286,8 +341,9 @@ template <typename Integer>
 std::optional<std::string> ComputeFFT(const Plan<Integer>& fft_plan, const DataBatchHandler<Integer>& data,
                                       const int /*max_no_optin_shared_mem*/ = 32768) {
   std::string err;
+  const auto tuned = tfft_detail::tuned_for_batch(fft_plan, static_cast<uint64_t>(data.amount_of_ffts_));
   tfft_plan* p = tfft_detail::exec_plan(static_cast<uint64_t>(fft_plan.fft_length_),
-                                        static_cast<uint64_t>(data.amount_of_ffts_), fft_plan.tfft_variant_, &err);
+                                        static_cast<uint64_t>(data.amount_of_ffts_), tuned.first, &err, tuned.second);
   if (!p) return err;
   __half* out_re = fft_plan.results_in_results_ ? data.dptr_results_RE_[0] : data.dptr_input_RE_[0];
   __half* out_im = fft_plan.results_in_results_ ? data.dptr_results_IM_[0] : data.dptr_input_IM_[0];
@@ -387,8 +443,9 @@ std::optional<std::string> ComputeFFTsMultiGPU(const Plan<Integer>& fft_plan, co
     if (!data.count_[i]) continue;
     if (hipSetDevice(data.device_ids_[i]) != hipSuccess) return std::string("hipSetDevice failed");
     std::string err;
+    const auto tuned = tfft_detail::tuned_for_batch(fft_plan, static_cast<uint64_t>(data.count_[i]));
     tfft_plan* p = tfft_detail::exec_plan(static_cast<uint64_t>(fft_plan.fft_length_), static_cast<uint64_t>(data.count_[i]),
-                                          fft_plan.tfft_variant_, &err);
+                                          tuned.first, &err, tuned.second);
     if (!p) return err;
     const int ii = static_cast<int>(i);
     __half* out = fft_plan.results_in_results_ ? data.results(ii) : data.input(ii);

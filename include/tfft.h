@@ -129,7 +129,15 @@ typedef struct tfft_plan_opts {
                            pass. What TFFT_ORDER_TRANSPOSED plans use internally and what a transform distributed over
                            several GPUs needs in front of its all-to-all (tensor-fft_amd/distributed.py) */
   uint64_t fourstep_col0;
+  uint32_t launch_iters; /* launch shape of the plan's grid-stride kernels, a tuner input (tools/tuner.py searches it per
+                           (N, batch) and writes it as the seventh column of the tuner file): 0 = the library's measured default
+                           per kernel; k = 1 .. 65534: a workgroup takes about k rounds of work (k transforms per wave of the
+                           single-pass kernels, k column blocks per workgroup of the column passes) and retires, the hardware
+                           dispatcher refilling CUs as they drain (at least one workgroup per CU while there is that much
+                           work); TFFT_LAUNCH_PERSISTENT: one workgroup per CU for the whole batch. Never changes results (the
+                           kernels stride over the batch): the best shape at batch 65536 is not the best at batch 64. */
 } tfft_plan_opts;
+enum { TFFT_LAUNCH_PERSISTENT = 65535 };
 
 /* tfft_plan_opts.scale — where the 1/N goes. The reference ships "sequential scaling" and keeps the other two as
  * commented-out variants (src/base/TensorFFT256.cu:163-177 "For unscaled results" / "For scaling in one step",
@@ -179,10 +187,13 @@ int tfft_plan_describe(uint64_t n, uint64_t inner, int variant, char* buf, size_
 
 /* Number of passes over the data one tfft_exec makes (= kernel launches, except that a narrow column pass with a
  * ragged batch takes two) and the bytes of device scratch it needs beyond in/out (0 for N <= 32768 with a contiguous axis). If nonzero, either hand memory in
- * with tfft_plan_set_workspace() or let the first tfft_exec hipMalloc it. */
+ * with tfft_plan_set_workspace(), call tfft_plan_prepare() once, or let the first tfft_exec hipMalloc it. */
 int tfft_plan_num_launches(const tfft_plan* plan);
 size_t tfft_plan_workspace_bytes(const tfft_plan* plan);
 int tfft_plan_set_workspace(tfft_plan* plan, void* device_ptr, size_t bytes);
+/* Allocates the plan's own workspace NOW (no-op when it needs none or one was handed in), so that no later tfft_exec calls
+ * hipMalloc: with it, execution is launches only from the first call on. */
+int tfft_plan_prepare(tfft_plan* plan);
 
 /* Replaces ComputeFFT(Plan&, const DataHandler&, int) and ComputeFFT(const Plan&,
  * const DataBatchHandler&, int) (src/base/ComputeFFT.h:54-151, 162-293): enqueues
@@ -288,6 +299,14 @@ int tfft_dist_exec_pre(const tfft_dist_plan* plan, const void* in_re, const void
 int tfft_dist_exec_exchange(const tfft_dist_plan* plan, void* stream);
 int tfft_dist_exec_post(const tfft_dist_plan* plan, void* out_re, void* out_im, void* stream);
 int tfft_dist_exec(const tfft_dist_plan* plan, const void* in_re, const void* in_im, void* out_re, void* out_im, void* stream);
+
+/* Host <-> device copies of pageable host memory through a ring of pinned staging buffers (chunked hipMemcpyAsync on a private
+ * stream, the host-side copies on a few threads): what DataHandler / DataBatchHandler::CopyDataHostToDevice and
+ * CopyResultsDeviceToHost of the C++ shim use in place of the reference's single blocking cudaMemcpy
+ * (src/base/DataHandler.h:45-70,116-153). Blocking like it: on return the bytes are where they were sent. The device is the
+ * current device. tfft_copy_d2h first waits for the device to finish (as a blocking hipMemcpy does). */
+int tfft_copy_h2d(void* dst_device, const void* src_host, size_t bytes);
+int tfft_copy_d2h(void* dst_host, const void* src_device, size_t bytes);
 
 /* Layout adapters either side of the path: interleaved (re, im) half2 samples, as cuFFT / hipFFT callers and the
  * reference's comparison code hold them (src/testing/AccuracyCalculator.h:35-48, TestingDataCreation.h half2

@@ -24,8 +24,10 @@ SYMBOLS = [
     "tfft_dist_comm_destroy", "tfft_dist_group_start", "tfft_dist_group_end", "tfft_dist_plan_create",
     "tfft_dist_plan_destroy", "tfft_dist_plan_geometry", "tfft_dist_plan_buffers", "tfft_dist_plan_set_buffers",
     "tfft_dist_exec_pre", "tfft_dist_exec_exchange", "tfft_dist_exec_post", "tfft_dist_exec",
+    "tfft_copy_h2d", "tfft_copy_d2h", "tfft_plan_prepare",
 ]
 
+LAUNCH_PERSISTENT = 65535                                     # tfft_plan_opts.launch_iters
 SCALE_SEQUENTIAL, SCALE_NONE, SCALE_ONCE = 0, 1, 2           # tfft_plan_opts.scale
 ORDER_NATURAL, ORDER_TRANSPOSED = 0, 1                        # tfft_plan_opts.output_order
 _SCALES = {"sequential": 0, "none": 1, "once": 2}
@@ -70,6 +72,7 @@ class PlanOpts(ctypes.Structure):
         ("output_order", ctypes.c_int),
         ("fourstep_n", ctypes.c_uint64),
         ("fourstep_col0", ctypes.c_uint64),
+        ("launch_iters", ctypes.c_uint32),
     ]
 
 
@@ -202,6 +205,12 @@ def load_library():
     L.tfft_dist_exec_post.argtypes = [vp, vp, vp, vp]
     L.tfft_dist_exec.restype = ci
     L.tfft_dist_exec.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.tfft_copy_h2d.restype = ci
+    L.tfft_copy_h2d.argtypes = [vp, vp, ctypes.c_size_t]
+    L.tfft_copy_d2h.restype = ci
+    L.tfft_copy_d2h.argtypes = [vp, vp, ctypes.c_size_t]
+    L.tfft_plan_prepare.restype = ci
+    L.tfft_plan_prepare.argtypes = [vp]
     L.tfft_last_error.restype = ctypes.c_char_p
     L.tfft_last_error.argtypes = []
     L.tfft_version.restype = ctypes.c_char_p
@@ -253,14 +262,15 @@ class TfftPlan:
     """Owning wrapper of tfft_plan. exec() takes torch CUDA half tensors (planar)."""
 
     def __init__(self, n, batch=1, device=0, in_batch_stride=0, out_batch_stride=0, preserve_input=False,
-                 variant=0, inner=1, scale="sequential", output_order="natural", fourstep_n=0, fourstep_col0=0):
+                 variant=0, inner=1, scale="sequential", output_order="natural", fourstep_n=0, fourstep_col0=0,
+                 launch_iters=0):
         L = load_library()
         self._lib = L
         self._h = ctypes.c_void_p()
         scale = _SCALES[scale] if isinstance(scale, str) else int(scale)
         output_order = _ORDERS[output_order] if isinstance(output_order, str) else int(output_order)
         opts = PlanOpts(int(in_batch_stride), int(out_batch_stride), int(inner), int(bool(preserve_input)), int(variant),
-                        scale, output_order, int(fourstep_n), int(fourstep_col0))
+                        scale, output_order, int(fourstep_n), int(fourstep_col0), int(launch_iters))
         self.scale, self.output_order = scale, output_order
         _check(L.tfft_plan_create(int(n), int(batch), int(device), ctypes.byref(opts), ctypes.byref(self._h)))
         self.n, self.batch, self.device, self.inner = int(n), int(batch), int(device), int(inner)

@@ -136,6 +136,7 @@ struct tfft_plan {
   bool preserve_input = false;
   int num_cus = 0;
   int variant = 0;
+  uint32_t launch_iters = 0;    // tfft_plan_opts.launch_iters
   // output re-mapping of a single radix-512 column pass (second pass of the fused 2D plan, see tfft_plan2d_create)
   uint32_t out_row_shift = 0, out_sub_shift = 0;
   uint64_t out_sub_stride = 0;
@@ -314,6 +315,12 @@ inline uint32_t env_iters(const char* name, uint32_t dflt) {
   return dflt;
 #endif
 }
+// tfft_plan_opts.launch_iters -> rounds per workgroup: 0 keeps the kernel's measured default, TFFT_LAUNCH_PERSISTENT one
+// workgroup per CU for the whole batch
+inline uint32_t plan_iters(uint32_t launch_iters, uint32_t dflt) {
+  if (launch_iters == 0) return dflt;
+  return launch_iters >= TFFT_LAUNCH_PERSISTENT ? 1000000u : launch_iters;
+}
 inline uint32_t pick_grid(uint64_t blocks_needed, int num_cus, uint32_t iters) {
   const uint64_t lo = std::min<uint64_t>(blocks_needed, static_cast<uint64_t>(num_cus));
   return static_cast<uint32_t>(std::max<uint64_t>(lo, (blocks_needed + iters - 1) / std::max(iters, 1u)));
@@ -328,8 +335,8 @@ int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, voi
   // the first one's stores, and the hardware dispatcher hands out the remaining workgroups as CUs drain, which keeps
   // the CUs out of lock-step (measured: 256 persistent workgroups 5.3 TB/s, two transforms per wave 6.1 TB/s, one
   // transform per wave 5.1 TB/s; profiles/r1_k4096_grid_scan.txt).
-  static const uint32_t iters_env = env_iters("TFFT_K4096_ITERS", 0);   // experiment knob
-  const uint32_t iters = iters_env ? iters_env : (blocks_needed >= 4u * static_cast<uint32_t>(p->num_cus) ? 2u : 1u);
+  static const uint32_t iters_env = env_iters("TFFT_K4096_ITERS", 0);   // experiment knob (debug build only)
+  const uint32_t iters = iters_env ? iters_env : plan_iters(p->launch_iters, blocks_needed >= 4u * static_cast<uint32_t>(p->num_cus) ? 2u : 1u);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
   TFFT_LAUNCH(k4096::fft4096_kernel<V>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
@@ -342,8 +349,8 @@ int launch_k256(const tfft_plan* p, const void* in_re, const void* in_im, void* 
                 k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   const uint64_t groups = (p->batch + k256::kFftsPerWave - 1) / k256::kFftsPerWave;
   const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
-  static const uint32_t iters = env_iters("TFFT_K256_ITERS", 2);
-  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
+  static const uint32_t iters_dflt = env_iters("TFFT_K256_ITERS", 2);
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
   TFFT_LAUNCH(k256::fft256_kernel, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
@@ -356,8 +363,8 @@ int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, voi
                    k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   const uint64_t groups = (p->batch + (16 / R) - 1) / (16 / R);
   const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
-  static const uint32_t iters = env_iters("TFFT_K256_ITERS", 2);
-  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
+  static const uint32_t iters_dflt = env_iters("TFFT_K256_ITERS", 2);
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
   TFFT_LAUNCH((k256r::fft256r_kernel<R, STG>), dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
@@ -388,8 +395,8 @@ int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, vo
   const uint32_t blocks_needed = static_cast<uint32_t>((p->batch + per_wg - 1) / per_wg);
   // persistent workgroups: with four workgroup barriers per transform the short-lived launch shape of the 4096
   // kernel does not help here (measured at 2^13: 405 / 425 / 440 / 457 Gsamples/s for 1 / 2 / 4 / all iterations)
-  static const uint32_t iters = env_iters("TFFT_K4096R_ITERS", 1000000);   // experiment knob
-  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
+  static const uint32_t iters_dflt = env_iters("TFFT_K4096R_ITERS", 1000000);   // experiment knob (debug build only)
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
   TFFT_LAUNCH(k4096r::fft4096r_kernel<R>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
@@ -443,8 +450,8 @@ struct Planes {
 template <int MODE, int TW, bool STAGE, bool LUT>
 int launch_col_t(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   const uint32_t blocks_needed = (a.tasks + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock;
-  static const uint32_t iters = env_iters("TFFT_COL_ITERS", 1000000);
-  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
+  static const uint32_t iters_dflt = env_iters("TFFT_COL_ITERS", 1000000);
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
   TFFT_LAUNCH((colfft::colfft256_kernel<MODE, TW, STAGE, LUT>), dim3(grid), dim3(k4096::kThreads), colfft::kLdsBytes, s, a);
   return TFFT_OK;
 }
@@ -453,8 +460,8 @@ template <int MODE, int TW, bool NT, int W, bool STG = false>
 int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   using G = colfft::WgGeom<W>;
   const uint64_t blocks = (a.tasks / a.groups) * a.pitch / G::kCols;
-  static const uint32_t iters = env_iters("TFFT_COLWG_ITERS", 1000000);
-  const uint32_t grid = pick_grid(blocks, p->num_cus * (8 / W), iters);
+  static const uint32_t iters_dflt = env_iters("TFFT_COLWG_ITERS", 1000000);
+  const uint32_t grid = pick_grid(blocks, p->num_cus * (8 / W), plan_iters(p->launch_iters, iters_dflt));
   TFFT_LAUNCH((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid), dim3(G::kThreadsW), G::kLds, s, a);
   return TFFT_OK;
 }
@@ -537,7 +544,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   if (radix == 1024) {
     // (plan creation only emits this pass where the geometry fits: pitch, and ns_f unless it is 1, multiples of 64)
     const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
+    const uint32_t grid = pick_grid(blocks, p->num_cus, plan_iters(p->launch_iters, 1000000u));
     if (a.ns_f == 1) {
       if (ps.tw_next)
         TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
@@ -557,7 +564,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     // plan creation only emits this pass where the geometry fits (pitch, and ns_f unless it is 1, multiples of 64)
     const bool on_lanes = (a.ns_f == 1);
     const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(p->num_cus)));
+    const uint32_t grid = pick_grid(blocks, p->num_cus, plan_iters(p->launch_iters, 1000000u));
     if (on_lanes) {
       if (ps.tw_next)
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
@@ -954,6 +961,7 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   co.variant = (p->variant & kColBits) | (n1 == 512 ? 67108864 : 0);
   co.scale = mode == TFFT_SCALE_SEQUENTIAL ? TFFT_SCALE_SEQUENTIAL : TFFT_SCALE_NONE;
   co.fourstep_n = n;
+  co.launch_iters = p->launch_iters;
   int rc = create_plan(n1, p->batch, device_id, &co, InternalOpts{}, &p->sub_col);
   if (rc) return rc;
   tfft_plan_opts ro{};
@@ -961,6 +969,7 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   ro.out_batch_stride = n2;
   ro.preserve_input = 1;
   ro.scale = mode;
+  ro.launch_iters = p->launch_iters;
   ro.variant = p->variant & ((n2 == 4096 ? kVarK4096 : 0) | ((n2 == 512 || n2 == 1024 || n2 == 2048) ? 1048576 : 0));
   InternalOpts ri;
   ri.group_shift = static_cast<uint32_t>(ilog2(n1));
@@ -1017,6 +1026,7 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   p->out_stride = out_stride;
   p->preserve_input = opts && opts->preserve_input;
   p->variant = pvariant;
+  p->launch_iters = opts ? opts->launch_iters : 0;
   p->scale_mode = scale_mode;
   p->tw4_modulus = tw4;
   p->tw4_col0 = opts ? opts->fourstep_col0 : 0;
@@ -1188,6 +1198,17 @@ size_t tfft_plan_workspace_bytes(const tfft_plan* p) {
     if (!p || single_kernel(p)) return 0;
   }
   return static_cast<size_t>(p->batch) * p->n * p->inner * 4;   // [batch][RE | IM] halves
+}
+
+int tfft_plan_prepare(tfft_plan* p) {
+  g_err.clear();
+  if (!p) return fail(TFFT_ERR_ARG, "null plan");
+  int prev = 0;
+  TFFT_HIP(hipGetDevice(&prev));
+  TFFT_HIP(hipSetDevice(p->device));
+  const int rc = ensure_workspace(p);
+  (void)hipSetDevice(prev);
+  return rc;
 }
 
 int tfft_plan_set_workspace(tfft_plan* p, void* device_ptr, size_t bytes) {
@@ -1518,3 +1539,4 @@ double tfft_plan_mfma_flops(const tfft_plan* p) {
 }  // extern "C"
 
 #include "dist.hpp"
+#include "staging.hpp"

@@ -29,7 +29,7 @@ class Plan:
         "fft_length_", "amount_of_r16_steps_", "amount_of_r2_steps_", "base_fft_mode_", "results_in_results_",
         "base_fft_warps_per_block_", "base_fft_blocksize_", "base_fft_gridsize_", "base_fft_shared_mem_in_bytes_",
         "r16_warps_per_block_", "r16_blocksize_", "r16_gridsize_", "r16_shared_mem_in_bytes_", "r2_blocksize_",
-        "_exec_plans", "_variant",
+        "_exec_plans", "_variant", "_tuned",
     )
 
     def __init__(self, s):
@@ -49,6 +49,7 @@ class Plan:
         self.r2_blocksize_ = s.r2_blocksize
         self._exec_plans = {}
         self._variant = 0          # MI355X tuner knob (sixth column of a tuner file), 0 = default
+        self._tuned = []           # (batch, variant, launch_iters) per tuner-file line of this length (columns 6 - 8)
 
 
 def CreatePlan(fft_length, mode=Mode_256, base_fft_warps_per_block=8, r16_warps_per_block=8, r2_blocksize=256):
@@ -70,23 +71,37 @@ def _create_plan_from_file(fft_length, tuner_results_file):
     except OSError:
         print("Error! Failed to open tuner file.")
         return None
+    plan = None
     with f:
         for line in f:
             tok = line.split()
             if len(tok) < 5:
                 continue
-            if int(float(tok[0])) == fft_length:
+            if int(float(tok[0])) != fft_length:
+                continue
+            if plan is None:
                 mode = Mode_256 if int(tok[1]) == 256 else Mode_4096
                 plan = CreatePlan(fft_length, mode, int(tok[2]), int(tok[3]), int(tok[4]))
-                if plan is not None and len(tok) >= 6:      # tools/tuner.py appends the tuned kernel variant
-                    try:
-                        variant = int(tok[5])
-                        capi.variant_check(fft_length, 1, variant)     # unknown or WRONG-result bits: refuse the line
-                    except (ValueError, capi.TfftError) as e:
-                        print(f"Error! Tuner file holds an unusable kernel variant for this fft length: {e}")
-                        return None
+                if plan is None:
+                    return None
+            if len(tok) >= 6:      # tools/tuner.py appends: kernel variant [launch_iters [batch it was tuned at]]
+                try:
+                    variant = int(tok[5])
+                    iters = int(tok[6]) if len(tok) >= 7 else 0
+                    batch = int(tok[7]) if len(tok) >= 8 else 0
+                    capi.variant_check(fft_length, 1, variant)     # unknown or WRONG-result bits: refuse the line
+                    if not 0 <= iters <= 65535 or batch < 0:
+                        raise ValueError("launch_iters outside 0 .. 65535")
+                except (ValueError, capi.TfftError) as e:
+                    print(f"Error! Tuner file holds an unusable kernel variant for this fft length: {e}")
+                    return None
+                plan._tuned.append((batch, variant, iters))
+                if len(plan._tuned) == 1:
                     plan._variant = variant
-                return plan
+            else:
+                break              # a plain reference line: nothing more to read for this length
+    if plan is not None:
+        return plan
     print("Error! Tuner file didnt contain requested fft length.")
     return None
 
@@ -195,11 +210,25 @@ class DataBatchHandler:
         return None
 
 
+def tuned_for_batch(tuned, batch, default_variant=0):
+    """(variant, launch_iters) for a batch: the tuner-file line of this length whose batch is nearest on a log scale (lines
+    without a batch column count as tuned at every batch, with the lowest priority among ties)."""
+    import math
+
+    best, best_d = (default_variant, 0), None
+    for b, variant, iters in tuned:
+        d = abs(math.log2(max(batch, 1)) - math.log2(b)) if b > 0 else 1e9
+        if best_d is None or d < best_d:
+            best, best_d = (variant, iters), d
+    return best
+
+
 def _exec_plan(fft_plan, batch, device):
     key = (batch, device)
     p = fft_plan._exec_plans.get(key)
     if p is None:
-        p = capi.TfftPlan(fft_plan.fft_length_, batch, device, variant=fft_plan._variant)
+        variant, iters = tuned_for_batch(fft_plan._tuned, batch, fft_plan._variant)
+        p = capi.TfftPlan(fft_plan.fft_length_, batch, device, variant=variant, launch_iters=iters)
         fft_plan._exec_plans[key] = p
     return p
 

@@ -15,6 +15,13 @@ int main(int argc, char** argv) {
     return 0;
   }
   std::cout << "ok " << plan->tfft_variant_ << " " << plan->amount_of_r16_steps_ << " " << plan->amount_of_r2_steps_ << " "
-            << static_cast<int>(plan->base_fft_mode_) << std::endl;
+            << static_cast<int>(plan->base_fft_mode_);
+  // every (batch, variant, launch_iters) line of this length, then what a batch of argv[3] would run with
+  for (const auto& t : plan->tfft_tuned_) std::cout << " [" << t.batch << " " << t.variant << " " << t.launch_iters << "]";
+  if (argc > 3) {
+    const auto pick = tfft_detail::tuned_for_batch(*plan, static_cast<uint64_t>(std::atoll(argv[3])));
+    std::cout << " pick " << pick.first << " " << pick.second;
+  }
+  std::cout << std::endl;
   return 0;
 }

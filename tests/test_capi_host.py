@@ -252,17 +252,24 @@ def test_cxx_shim_tuner_file_overload_keeps_column_six(tmp_path, monkeypatch):
     f = tmp_path / "TunerResults.dat"
     f.write_text("4096 4096 16 4 128 10\n8192 256 8 16 256\n65536 4096 16 1 256 65536\n1048576 4096 16 1 256 524288\n")
 
-    def run(n):
-        return subprocess.run([exe, str(f), str(n)], capture_output=True, text=True, check=True).stdout.split("\n")[-2].split()
+    def run(n, *more):
+        return subprocess.run([exe, str(f), str(n), *more], capture_output=True, text=True, check=True).stdout.split("\n")[-2].split()
 
-    assert run(4096) == ["ok", "10", "2", "0", "1"]
-    assert run(8192) == ["ok", "0", "2", "1", "0"]
-    assert run(1 << 20) == ["ok", "524288", "4", "0", "1"]
+    assert run(4096)[:5] == ["ok", "10", "2", "0", "1"]
+    assert run(8192)[:5] == ["ok", "0", "2", "1", "0"]
+    assert run(1 << 20)[:5] == ["ok", "524288", "4", "0", "1"]
     assert run(65536) == ["refused"]
     assert run(1 << 22) == ["refused"]
     for n in (4096, 8192, 1 << 20):
         p = tf.CreatePlan(n, str(f))
-        assert [str(p._variant), str(p.amount_of_r16_steps_), str(p.amount_of_r2_steps_), str(p.base_fft_mode_)] == run(n)[1:]
+        assert [str(p._variant), str(p.amount_of_r16_steps_), str(p.amount_of_r2_steps_), str(p.base_fft_mode_)] == run(n)[1:5]
+    # columns 7 / 8 (launch_iters, batch): one entry per line of the length, the nearest batch wins
+    f.write_text("4096 4096 16 1 256 10 65535 1\n4096 4096 16 1 256 16 1 64\n4096 4096 16 1 256 10 2 65536\n8192 4096 16 1 256 0 70000 4\n")
+    assert " ".join(run(4096, "100")[5:]) == "[1 10 65535] [64 16 1] [65536 10 2] pick 16 1"
+    assert run(4096, "1")[-3:] == ["pick", "10", "65535"] and run(4096, "2000000")[-3:] == ["pick", "10", "2"]
+    assert run(8192) == ["refused"]
+    p = tf.CreatePlan(4096, str(f))
+    assert p._tuned == [(1, 10, 65535), (64, 16, 1), (65536, 10, 2)]
 
 
 def test_rotor_covers_every_item_once(tmp_path):
@@ -281,3 +288,23 @@ def test_reference_style_mains_compile_against_the_shim(tmp_path):
     for name in ("example_batch_fft", "example_single_fft"):
         _hipcc_host(os.path.join(ROOT, "examples", name + ".cpp"), str(tmp_path / name))
         assert os.path.getsize(tmp_path / name) > 0
+
+
+def test_tuner_file_with_batch_lines(tmp_path):
+    """Columns 7 and 8 of the tuner file (launch_iters, the batch a line was tuned at; tools/tuner.py --batches): CreatePlan
+    reads every line of the length, ComputeFFT takes the line nearest to its batch on a log scale."""
+    from tensor_fft_amd import reference_api as ra
+
+    f = tmp_path / "TunerResults.dat"
+    f.write_text("4096 4096 16 1 256 10 65535 1\n4096 4096 16 1 256 16 1 64\n4096 4096 16 1 256 10 2 65536\n"
+                 "8192 4096 16 1 256 0\n65536 4096 16 1 256 524288 70000 4\n")
+    p = tf.CreatePlan(4096, str(f))
+    assert p._tuned == [(1, 10, 65535), (64, 16, 1), (65536, 10, 2)] and p._variant == 10
+    assert ra.tuned_for_batch(p._tuned, 1) == (10, 65535)
+    assert ra.tuned_for_batch(p._tuned, 100) == (16, 1)
+    assert ra.tuned_for_batch(p._tuned, 20000) == (10, 2)
+    assert ra.tuned_for_batch(p._tuned, 1 << 21) == (10, 2)
+    q = tf.CreatePlan(8192, str(f))
+    assert q._tuned == [(0, 0, 0)] and ra.tuned_for_batch(q._tuned, 77) == (0, 0)
+    assert tf.CreatePlan(65536, str(f)) is None                      # launch_iters outside 0 .. 65535
+    assert ra.tuned_for_batch([], 5, default_variant=8) == (8, 0)

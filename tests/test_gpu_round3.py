@@ -1,0 +1,97 @@
+"""Round 3: launch shapes as plan options (tfft_plan_opts.launch_iters, the tuner's per-(N, batch) knob)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+REL_L2_TOL = 1.5e-3
+
+
+@pytest.fixture(scope="module")
+def tf():
+    import __graft_entry__ as g
+
+    g.build()
+    import tensor_fft_amd as t
+
+    t.device_check(0)
+    return t
+
+
+def _cases():
+    """Every kernel family at a batch that fills the chip several times over and at a small one, every launch_iters value
+    tools/tuner.py can emit (plus an odd one)."""
+    import tuner
+
+    out = []
+    for n, batches in ((256, (5, 20000)), (1024, (3, 9000)), (4096, (7, 5000)), (8192, (2, 700)), (1 << 15, (1, 130)),
+                       (1 << 16, (1, 70)), (1 << 18, (1, 33)), (1 << 20, (1, 17)), (1 << 22, (1, 3))):
+        for b in batches:
+            for it in sorted(set(tuner.iters_candidates()[1:] + [3])):
+                out.append((n, b, it))
+    return out
+
+
+@pytest.mark.parametrize("n,batch,iters", _cases())
+def test_launch_shape_never_changes_results(tf, orc, n, batch, iters):
+    """launch_iters re-shapes the grid only: spectra are bit-identical to the default shape's, whose first and last transforms
+    are checked against the CPU oracle."""
+    import torch
+
+    x = torch.empty(batch * 2 * n, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x, x[n:], n, batch, seed=n + batch)
+    outs = []
+    for it in (0, iters):
+        y = torch.full_like(x, float("nan"))
+        plan = tf.TfftPlan(n, batch, 0, preserve_input=True, launch_iters=it)
+        plan.exec(x, x[n:], y, y[n:])
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert bool((outs[0].view(torch.int16) == outs[1].view(torch.int16)).all()), (n, batch, iters)
+    for b in sorted({0, batch - 1}):
+        re, im = orc.synth_uniform(n, 1, b, n + batch)
+        e_re, e_im = orc.dft64(re, im)
+        o = outs[0][b * 2 * n:(b + 1) * 2 * n].cpu().numpy().astype(np.float64)
+        got, exact = o[:n] + 1j * o[n:], e_re[0] + 1j * e_im[0]
+        assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL
+
+
+def test_launch_shape_reaches_strided_axes_and_transposed_plans(tf):
+    import torch
+
+    rng = np.random.default_rng(9)
+    for kw, n, batch in (({"inner": 256}, 512, 3), ({"output_order": "transposed"}, 1 << 18, 5), ({"inner": 64}, 4096, 2)):
+        nf = n * kw.get("inner", 1)
+        x = torch.from_numpy(rng.uniform(-1, 1, batch * 2 * nf).astype(np.float16)).cuda()
+        want = None
+        for it in (0, 1, 2, 65535):
+            y = torch.full_like(x, float("nan"))
+            tf.TfftPlan(n, batch, 0, preserve_input=True, launch_iters=it, **kw).exec(x, x[nf:], y, y[nf:])
+            torch.cuda.synchronize()
+            if want is None:
+                want = y
+            assert bool((y.view(torch.int16) == want.view(torch.int16)).all()), (kw, it)
+
+
+def test_reference_api_uses_the_tuner_line_of_the_nearest_batch(tf, tmp_path):
+    """CreatePlan(N, tuner_file) + ComputeFFT(plan, DataBatchHandler): columns 7 / 8 of the file reach tfft_plan_opts."""
+    f = tmp_path / "TunerResults.dat"
+    f.write_text("4096 4096 16 1 256 16 65535 1\n4096 4096 16 1 256 10 1 64\n4096 4096 16 1 256 10 2 65536\n")
+    plan = tf.CreatePlan(4096, str(f))
+    rng = np.random.default_rng(4)
+    for batch in (1, 50, 3000):
+        host = rng.uniform(-1, 1, batch * 2 * 4096).astype(np.float16)
+        h = tf.DataBatchHandler(4096, batch)
+        assert h.CopyDataHostToDevice(host) is None
+        assert tf.ComputeFFT(plan, h) is None
+        out = np.empty_like(host)
+        assert h.CopyResultsDeviceToHost(out, plan.results_in_results_) is None
+        z = host.reshape(batch, 2, 4096).astype(np.float64)
+        exact = np.fft.fft(z[:, 0] + 1j * z[:, 1], axis=1) / 4096
+        o = out.reshape(batch, 2, 4096).astype(np.float64)
+        got = o[:, 0] + 1j * o[:, 1]
+        assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL

@@ -3,7 +3,7 @@ AccuracyTestBandwidth.cu:17-87, AccuracyTestCuFFT.cu, AccuracyTestBandwidthCuFFT
 
   (1) error vs N:          N = 2^8 .. 2^max, 256 harmonics (or N/2 if smaller), weights seeds 42 / 1764
   (2) error vs bandwidth:  N = 2^20, frequency cutoff 1, 2, 4, ..., N/2
-  each line: `x avg sigma max` of |delta| against the fp64 DFT(x)/N of the same fp16 input (the reference uses
+  each line: `x max avg sigma` of |delta| against the fp64 DFT(x)/N of the same fp16 input (the reference uses
   cuFFT Z2Z / N; here the CPU oracle), for three columns of transforms:
      ours       - this library on the MI355X
      reference  - the oracle's fp16 restatement of the reference CUDA kernels (N <= 2^20)
@@ -21,15 +21,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def stats(orc, got_re, got_im, ex_re, ex_im):
-    return orc.deviation_stats(np.asarray(got_re, dtype=np.float64), np.asarray(got_im, dtype=np.float64), ex_re, ex_im)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--outdir", default="profiles")
-    ap.add_argument("--max-log2", type=int, default=22)
-    ap.add_argument("--tag", default="r1")
+    ap.add_argument("--max-log2", type=int, default=28)
+    ap.add_argument("--tag", default="r3")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as g
@@ -37,33 +33,13 @@ def main():
     g.build()
     import tensor_fft_amd as tf
     from oracle import orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import accuracy_protocol as proto         # the protocol itself lives with the tests (it uses the CPU oracle)
 
-    w_re, w_im = orc.random_weights(1 << 20, 42), orc.random_weights(1 << 20, 1764)
+    w_re, w_im = proto.weights(orc)
 
     def run_all(n, cutoff):
-        re, im = orc.sine_superposition(n, w_re, w_im, cutoff)
-        ex_re, ex_im = orc.dft64(re, im)
-        ex_re, ex_im = ex_re[0], ex_im[0]
-        dev = torch.from_numpy(np.concatenate([re, im])).cuda()
-        out = torch.empty_like(dev)
-        tf.TfftPlan(n, 1, 0, preserve_input=True).exec(dev, dev[n:], out, out[n:])   # dev is reused below
-        torch.cuda.synchronize()
-        o = out.cpu().numpy()
-        res = {"ours": stats(orc, o[:n], o[n:], ex_re, ex_im)}
-        if n <= (1 << 20):
-            r = orc.ref_fft(re, im, orc.MODE_4096 if n >= 4096 else orc.MODE_256)
-            res["reference"] = stats(orc, r[0][0], r[1][0], ex_re, ex_im)
-        z = torch.complex(dev[:n].float(), dev[n:].float())
-        f32 = (torch.fft.fft(z) / n).cpu().numpy()
-        res["vendor_fp32"] = stats(orc, f32.real, f32.imag, ex_re, ex_im)
-        try:
-            zh = torch.complex(dev[:n], dev[n:])            # complex32
-            f16 = torch.fft.fft(zh)
-            f16 = (torch.view_as_real(f16).float() / n).cpu().numpy()
-            res["vendor_fp16"] = stats(orc, f16[:, 0], f16[:, 1], ex_re, ex_im)
-        except Exception:                                   # noqa: BLE001  (half FFT unavailable in this build)
-            pass
-        return res
+        return proto.run_point(torch, tf, orc, n, cutoff, w_re, w_im)
 
     os.makedirs(args.outdir, exist_ok=True)
     cols = ["ours", "reference", "vendor_fp16", "vendor_fp32"]
@@ -82,7 +58,7 @@ def main():
     with open(os.path.join(args.outdir, f"{args.tag}_accuracy_vs_bandwidth.dat"), "w") as f:
         f.write("# cutoff (N = 2^20)  then (max avg sigma) for: " + " | ".join(cols) + "\n")
         cutoff = 1
-        while cutoff <= n // 2:
+        while cutoff <= n // 2:          # 1, 4, 16, ..., N/4 (the signal generator costs N * cutoff sines)
             res = run_all(n, cutoff)
             row = [str(cutoff)]
             for c in cols:

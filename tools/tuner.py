@@ -4,9 +4,12 @@
 The reference searches (mode, base_fft_warps_per_block, r16_warps_per_block, r2_blocksize) and writes
 `N mode a b c` lines that CreatePlan(N, file) reads back (Plan.h:197-255). On MI355X those launch-geometry
 knobs do not exist; what can be tuned is the kernel variant of the N = 4096 path and, for other lengths,
-the pass decomposition (radix-256 column passes vs the plain radix-16 autosort chain). The file keeps the
-reference's five columns (still valid input for its own parser, which ignores further tokens) and appends
-the tuned `variant` as a sixth column, which this repo's CreatePlan(N, file) honours.
+the pass decomposition (radix-256 column passes vs the plain radix-16 autosort chain), and for every kernel its launch
+shape (tfft_plan_opts.launch_iters: short-lived against persistent workgroups), which depends on the batch. The file keeps
+the reference's five columns (still valid input for its own parser, which ignores further tokens) and appends
+`variant launch_iters batch` as columns six to eight: one line per (N, batch) with --batches (the MI355X counterpart of
+TunerBatchFFTs.cu:10-55). This repo's CreatePlan(N, file) reads all lines of a length and ComputeFFT uses the one whose
+batch is nearest to the batch it runs.
 
     python tools/tuner.py [--out TunerResults.dat] [--min-log2 8] [--max-log2 24] [--samples 20] [--warmup 5]
 """
@@ -35,6 +38,20 @@ def candidates(n):
     return [0, 32, 524288, 2097152, 1048576, 8388608, 33554432, 8388608 | 33554432, 134217728]
 
 
+def iters_candidates():
+    """tfft_plan_opts.launch_iters values tried per (N, batch) on the winning variant: 0 = the library's default shape, k = a
+    workgroup takes about k rounds and retires, 65535 = persistent workgroups. Launch shapes never change results
+    (tests/test_gpu_round3.py runs every value here against the default bit for bit)."""
+    return [0, 1, 2, 4, 65535]
+
+
+def batches_for(n, total_log2):
+    """Batch sizes a length is tuned at (the reference tunes one async batch size, TunerBatchFFTs.cu:10-55; the best launch
+    shape on MI355X depends on how many workgroups the batch fills the 256 CUs with): 1, 64, 4096 and 2^total / N."""
+    big = max(1, (1 << total_log2) // n)
+    return sorted({b for b in (1, 64, 4096, big) if b <= big})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="TunerResults.dat")
@@ -42,7 +59,9 @@ def main():
     ap.add_argument("--max-log2", type=int, default=24)
     ap.add_argument("--samples", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--total-log2", type=int, default=26, help="batch = 2^total / N transforms per timing")
+    ap.add_argument("--total-log2", type=int, default=26, help="largest batch = 2^total / N transforms per timing")
+    ap.add_argument("--batches", action="store_true", help="tune every length at several batch sizes (1, 64, 4096, 2^total / N): "
+                                                           "one file line per (N, batch)")
     args = ap.parse_args()
 
     import torch
@@ -51,38 +70,45 @@ def main():
     g.build()
     import tensor_fft_amd as tf
 
+    def time_plan(n, batch, x, y, v, iters):
+        try:
+            plan = tf.TfftPlan(n, batch, 0, variant=v, preserve_input=True, launch_iters=iters)
+        except tf.TfftError:
+            return None
+        ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+        if plan.workspace_bytes:
+            plan.set_workspace(ws)
+        ts = []
+        for k in range(args.warmup + args.samples):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            plan.exec(x, x[n:], y, y[n:])
+            e1.record()
+            torch.cuda.synchronize()
+            if k >= args.warmup:
+                ts.append(e0.elapsed_time(e1) * 1e6)           # ns, like the reference's timer
+        avg, sig = statistics.mean(ts), (statistics.stdev(ts) if len(ts) > 1 else 0.0)
+        print(f"N=2^{lg} batch={batch} variant={v:2d} iters={iters:5d} launches={plan.num_launches} avg {avg/1e3:9.1f} us "
+              f"sigma {sig/1e3:7.1f} us {n * batch / avg:7.2f} Gsamples/s", flush=True)
+        return avg
+
     lines = []
     for lg in range(args.min_log2, args.max_log2 + 1):
         n = 1 << lg
-        batch = max(1, (1 << args.total_log2) // n)
-        x = (torch.rand(batch * 2 * n, device="cuda") * 2 - 1).half()
-        y = torch.empty_like(x)
-        cands = candidates(n)
-        best = None
-        for v in cands:
-            try:
-                plan = tf.TfftPlan(n, batch, 0, variant=v, preserve_input=True)
-            except tf.TfftError:
-                continue
-            ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
-            if plan.workspace_bytes:
-                plan.set_workspace(ws)
-            ts = []
-            for k in range(args.warmup + args.samples):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                plan.exec(x, x[n:], y, y[n:])
-                e1.record()
-                torch.cuda.synchronize()
-                if k >= args.warmup:
-                    ts.append(e0.elapsed_time(e1) * 1e6)           # ns, like the reference's timer
-            avg, sig = statistics.mean(ts), (statistics.stdev(ts) if len(ts) > 1 else 0.0)
-            print(f"N=2^{lg} batch={batch} variant={v:2d} launches={plan.num_launches} avg {avg/1e3:9.1f} us sigma {sig/1e3:7.1f} us "
-                  f"{n * batch / avg:7.2f} Gsamples/s")
-            if best is None or avg < best[0]:
-                best = (avg, v)
-        mode = 4096 if n >= 4096 else 256
-        lines.append(f"{n} {mode} {16 if mode == 4096 else 1} 1 256 {best[1]}")
+        for batch in (batches_for(n, args.total_log2) if args.batches else [max(1, (1 << args.total_log2) // n)]):
+            x = (torch.rand(batch * 2 * n, device="cuda") * 2 - 1).half()
+            y = torch.empty_like(x)
+            best = None
+            for v in candidates(n):
+                avg = time_plan(n, batch, x, y, v, 0)
+                if avg is not None and (best is None or avg < best[0]):
+                    best = (avg, v, 0)
+            for it in iters_candidates()[1:]:
+                avg = time_plan(n, batch, x, y, best[1], it)
+                if avg is not None and avg < 0.98 * best[0]:       # a different shape has to win by more than the noise
+                    best = (avg, best[1], it)
+            mode = 4096 if n >= 4096 else 256
+            lines.append(f"{n} {mode} {16 if mode == 4096 else 1} 1 256 {best[1]} {best[2]} {batch}")
     with open(args.out, "w") as f:
         f.write("\n".join(lines) + "\n")
     print(f"wrote {args.out}")
