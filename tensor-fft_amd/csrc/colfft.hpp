@@ -595,11 +595,15 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         // row k = ka + 16 kb (kb = x) of the shared output image, this wave's columns 16 wave + 4g .. + 3:
         // chunk 2 wave + (g >> 1), bytes 8 (g & 1) of it. The OUTPUT image has its own swizzle, slot ^ kb over all four
         // bits of kb: the 16 lanes of a group then hit 16 different slots (with the input image's 2 (kb & 7), lanes kb
-        // and kb + 8 collided: PMC showed bank-conflict cycles = 54 % of the LDS-active cycles of this kernel)
+        // and kb + 8 collided: PMC showed bank-conflict cycles = 54 % of the LDS-active cycles of this kernel). Within the
+        // slot the 8-byte piece of an even / odd g takes the lower / upper half for kb < 8 and the other way round for kb >= 8:
+        // a ds_write_b64 is banked modulo 32 dwords over 16-lane groups, so pieces 128 bytes apart (kb, kb + 8) in the SAME
+        // half still collided 2-way on every store (all of the remaining SQ_LDS_BANK_CONFLICT of the column kernels in round 2,
+        // 20-25 % of their LDS-active cycles); the read-out swaps the halves back for rows with kb >= 8.
         const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
         const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
         uint8_t* dst = img + ((ka / kRps) + (16 / kRps) * x) * 256 +
-                       16 * (((ka % kRps) * kCpr + 2 * wave + (g >> 1)) ^ x) + 8 * (g & 1);
+                       16 * (((ka % kRps) * kCpr + 2 * wave + (g >> 1)) ^ x) + 8 * ((g & 1) ^ (x >> 3));
         *reinterpret_cast<u2*>(dst) = vr;
         *reinterpret_cast<u2*>(dst + kPlane) = vi;
       } else {
@@ -667,8 +671,12 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         const uint32_t v = (lane & 15) ^ (((sr * kRps) >> 4) & 15);   // output image: slot ^ kb (see the stage-2 stores)
         const uint32_t k = sr * kRps + v / kCpr;
         const uint32_t chunk = v % kCpr;
-        const u4 vr = *reinterpret_cast<const u4*>(img + 8192 * wave + 1024 * i + 16 * lane);
-        const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 8192 * wave + 1024 * i + 16 * lane);
+        u4 vr = *reinterpret_cast<const u4*>(img + 8192 * wave + 1024 * i + 16 * lane);
+        u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 8192 * wave + 1024 * i + 16 * lane);
+        if (k & 128) {                                                // kb >= 8: the two 8-byte halves were stored flipped
+          vr = u4{vr.z, vr.w, vr.x, vr.y};
+          vi = u4{vi.z, vi.w, vi.x, vi.y};
+        }
         const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
         if (NT) {
           __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(o_re + o));
@@ -836,7 +844,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
         const u2 vr = {pk(e_re[0], e_re[1]), pk(e_re[2], e_re[3])};
         const u2 vi = {pk(e_im[0], e_im[1]), pk(e_im[2], e_im[3])};
         uint8_t* dst = img_q + ((ka / kRps) + (16 / kRps) * x) * 256 +
-                       16 * (((ka % kRps) * kCpr + 2 * w4 + (g >> 1)) ^ x) + 8 * (g & 1);
+                       16 * (((ka % kRps) * kCpr + 2 * w4 + (g >> 1)) ^ x) + 8 * ((g & 1) ^ (x >> 3));
         *reinterpret_cast<u2*>(dst) = vr;
         *reinterpret_cast<u2*>(dst + kPlaneAll) = vi;
       } else if ((ka & 1) == 0) {
@@ -865,6 +873,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // C: A_0 and A_1 are complete
+    // (issued here, not at the top of the tile: with the loads in flight under the whole tile the pass ran 6 % SLOWER, 1707
+    // against 1613 us for 8 GiB, although it then needs fewer registers; the pass already moves data at the rate a plain copy
+    // with its 128-byte row segments reaches, 5.3-5.4 TB/s, profiles/r3_stride_pad.txt, and more requests in flight only
+    // lengthen the queues)
     if (rot.peek() < total) issue_loads(rot.peek());               // the next block's input starts flying now
 
     if (MODE == kColsOnLanes) {
@@ -945,10 +957,16 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       const uint32_t v = (L & 15) ^ (((sr * kRps) >> 4) & 15);   // output image: slot ^ kb
       const uint32_t k = sr * kRps + v / kCpr;
       const uint32_t chunk = v % kCpr;
-      const u4 a_re = *reinterpret_cast<const u4*>(img + 16 * L);
-      const u4 b_re = *reinterpret_cast<const u4*>(img + kHalf + 16 * L);
-      const u4 a_im = *reinterpret_cast<const u4*>(img + kPlaneAll + 16 * L);
-      const u4 b_im = *reinterpret_cast<const u4*>(img + kPlaneAll + kHalf + 16 * L);
+      u4 a_re = *reinterpret_cast<const u4*>(img + 16 * L);
+      u4 b_re = *reinterpret_cast<const u4*>(img + kHalf + 16 * L);
+      u4 a_im = *reinterpret_cast<const u4*>(img + kPlaneAll + 16 * L);
+      u4 b_im = *reinterpret_cast<const u4*>(img + kPlaneAll + kHalf + 16 * L);
+      if (k & 128) {                                                  // kb >= 8: the two 8-byte halves were stored flipped
+        a_re = u4{a_re.z, a_re.w, a_re.x, a_re.y};
+        b_re = u4{b_re.z, b_re.w, b_re.x, b_re.y};
+        a_im = u4{a_im.z, a_im.w, a_im.x, a_im.y};
+        b_im = u4{b_im.z, b_im.w, b_im.x, b_im.y};
+      }
       const h8 ar = __builtin_bit_cast(h8, a_re), br = __builtin_bit_cast(h8, b_re);
       const h8 ai = __builtin_bit_cast(h8, a_im), bi = __builtin_bit_cast(h8, b_im);
       const uint64_t o0 = obase + (static_cast<uint64_t>(k) << row_shift) + 8 * chunk;

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
             const u2 vr = {pk(sr[0], sr[1]), pk(sr[2], sr[3])};
             const u2 vi = {pk(si[0], si[1]), pk(si[2], si[3])};
             uint8_t* dst = img_q + ((ka / kRps) + (16 / kRps) * xl) * 256 +
-                           16 * (((ka % kRps) * kCpr + 2 * w4 + (gl >> 1)) ^ xl) + 8 * (gl & 1);
+                           16 * (((ka % kRps) * kCpr + 2 * w4 + (gl >> 1)) ^ xl) + 8 * ((gl & 1) ^ (xl >> 3));
             *reinterpret_cast<u2*>(dst) = vr;
             *reinterpret_cast<u2*>(dst + kPlaneAll) = vi;
           }
@@ -381,10 +381,15 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
         const uint32_t v = (L & 15) ^ (((sr * kRps) >> 4) & 15);   // output image: slot ^ kb
         const uint32_t k = sr * kRps + v / kCpr + 256 * j;
         const uint32_t chunk = v % kCpr;
-        const h8 ar = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + 16 * L));
-        const h8 br = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + kHalf + 16 * L));
-        const h8 ai = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + kPlaneAll + 16 * L));
-        const h8 bi = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(img + kPlaneAll + kHalf + 16 * L));
+        // (rows with kb >= 8 were staged with their two 8-byte halves flipped, see colfft256_wg_kernel's stage-2 stores)
+        auto ld = [&](const uint8_t* ptr) {
+          const u4 v4 = *reinterpret_cast<const u4*>(ptr);
+          return __builtin_bit_cast(h8, (k & 128) ? u4{v4.z, v4.w, v4.x, v4.y} : v4);
+        };
+        const h8 ar = ld(img + 16 * L);
+        const h8 br = ld(img + kHalf + 16 * L);
+        const h8 ai = ld(img + kPlaneAll + 16 * L);
+        const h8 bi = ld(img + kPlaneAll + kHalf + 16 * L);
         const uint64_t o0 = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
         const uint64_t o1 = o0 + (static_cast<uint64_t>(512) << a.ns_f_shift);
         if (TW == kTwNone && !SC) {
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
       for (int ka = 0; ka < 16; ++ka) {
         const int o = 2 * (ka & 1);
         uint8_t* dst = img_q + ((ka / kRps) + (16 / kRps) * xl) * 256 +
-                       16 * (((ka % kRps) * kCpr + 2 * w4 + (gl >> 1)) ^ xl) + 8 * (gl & 1);
+                       16 * (((ka % kRps) * kCpr + 2 * w4 + (gl >> 1)) ^ xl) + 8 * ((gl & 1) ^ (xl >> 3));
         *reinterpret_cast<u2*>(dst) = u2{sv_re[ka >> 1][o], sv_re[ka >> 1][o + 1]};
         *reinterpret_cast<u2*>(dst + kPlaneAll) = u2{sv_im[ka >> 1][o], sv_im[ka >> 1][o + 1]};
       }

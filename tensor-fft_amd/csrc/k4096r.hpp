@@ -271,8 +271,12 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         // read-out below touches 2-, 4- or 8-byte pieces, so the 4096 kernel's slot swizzle is not used here
         // (R = 8, 1D: the 32-byte unit k1 of a row sits at unit k1 ^ s, so that the transposed read-out below, which
         // takes the same 32 bytes from all 8 regions at once, finds them in 8 different bank groups)
+        // (2D rows: each wave reads its own region back as plain rows, so the 4096 kernel's slot swizzle applies: slot index
+        // XOR bit 3 of itself, which puts lanes k1 and k1 + 4 of one 8-lane ds_write_b128 group on different banks; the plain
+        // layout cost a 2-way conflict on every staging store: 20 % of this kernel's LDS-active cycles in round 2)
         const uint32_t k1s = (R == 8 && !ROWS) ? ((lane & 15) ^ s) : (lane & 15);
-        const uint32_t off = 16u * (2u * k1s + half) + 512u * (4 * g + r2);
+        const uint32_t slot = 2u * k1s + half;
+        const uint32_t off = 16u * (ROWS ? (slot ^ ((slot >> 3) & 1u)) : slot) + 512u * (4 * g + r2);
         *reinterpret_cast<u4*>(wl + off) = u4{ore[r2][0], ore[r2][1], ore[r2][2], ore[r2][3]};
         *reinterpret_cast<u4*>(wl + 8192 + off) = u4{oim[r2][0], oim[r2][1], oim[r2][2], oim[r2][3]};
       }
@@ -284,8 +288,9 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       uint16_t* const row_im = out_im + out_map.off(b) + static_cast<uint64_t>(512 * s + r0) * 4096;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const u4 vr = *reinterpret_cast<const u4*>(wl + 1024 * i + 16 * lane);
-        const u4 vi = *reinterpret_cast<const u4*>(wl + 8192 + 1024 * i + 16 * lane);
+        const uint32_t rd = 16u * (lane ^ ((lane >> 3) & 1));
+        const u4 vr = *reinterpret_cast<const u4*>(wl + 1024 * i + rd);
+        const u4 vi = *reinterpret_cast<const u4*>(wl + 8192 + 1024 * i + rd);
         *reinterpret_cast<u4*>(row_re + 512 * i + 8 * lane) = vr;
         *reinterpret_cast<u4*>(row_im + 512 * i + 8 * lane) = vi;
       }

@@ -25,6 +25,7 @@
 #include "k4096r.hpp"
 #include "colfft.hpp"
 #include "colfft1024.hpp"
+#include "colfft512r.hpp"
 #include "permute.hpp"
 #include "stockham.hpp"
 #include "synth.hpp"
@@ -58,7 +59,7 @@ inline int ilog2(uint64_t x) {
 constexpr int kVarK4096 = 1 | 2 | 8 | 16;
 constexpr int kVarDebug = 4 | 64 | 128 | 65536 | (15 << 8);
 constexpr int kVarTuner = kVarK4096 | 32 | 4096 | 8192 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 |
-                          8388608 | 16777216 | 33554432 | 67108864 | 134217728;
+                          8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456;
 // The shipped libtfft.so holds NO timing-only kernel, no environment knob and no measurement hook: all of that is compiled
 // only with -DTFFT_DEBUG_KERNELS (tensor-fft_amd/libtfft_debug.so, built on demand for the drivers under tools/), and even
 // there the debugging bits need TFFT_DEBUG_VARIANTS=1 in the environment of the process that creates the plan.
@@ -575,7 +576,15 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwFourStep>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
       else if (ps.tw_next)
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
-      else if (ps.scale != 1.0f)         // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out
+      else if (p->variant & 268435456) {
+        // variant bit 268435456: last pass of a plan / 2D column pass by the two-round kernel, two 4-wave workgroups per CU
+        // (colfft512r.hpp; measured 2-3 % behind the 8-wave kernel on MI355X, kept as a tuner alternative)
+        const uint32_t grid2 = pick_grid(blocks, 2 * p->num_cus, plan_iters(p->launch_iters, 1000000u));
+        if (ps.scale != 1.0f)            // TFFT_SCALE_ONCE: the single factor in fp32 at the combine
+          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<true>), dim3(grid2), dim3(colfft::kWg512rThreads), colfft::kWg512rLdsBytes, s, a);
+        else
+          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<false>), dim3(grid2), dim3(colfft::kWg512rThreads), colfft::kWg512rLdsBytes, s, a);
+      } else if (ps.scale != 1.0f)       // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
       else
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);

@@ -55,7 +55,7 @@ void run(const uint8_t* in, uint8_t* out, uint64_t pitch, uint64_t plane_bytes, 
   constexpr int ROWS = 65536 / SEG;
   const uint64_t entry = ROWS * pitch;                   // one transform: ROWS rows of pitch bytes
   const uint32_t bpe = static_cast<uint32_t>(pitch / SEG);
-  const uint32_t entries = static_cast<uint32_t>(plane_bytes / entry);
+  const uint32_t entries = static_cast<uint32_t>((1ull << 30) / entry);
   const uint32_t total = entries * bpe;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k<SEG>, dim3(256), dim3(512), 0, 0, in, out, pitch, bpe, total, entry, plane_bytes, pair);
@@ -69,11 +69,24 @@ void run(const uint8_t* in, uint8_t* out, uint64_t pitch, uint64_t plane_bytes, 
   (void)nt_off;
 }
 
-int main() {
+int main(int argc, char** argv) {
   const uint64_t plane = 1ull << 30;
   uint8_t *in, *out;
-  hipMalloc(&in, 2 * plane); hipMalloc(&out, 2 * plane);
+  hipMalloc(&in, 2 * plane + (64 << 20)); hipMalloc(&out, 2 * plane + (64 << 20));
   hipMemset(in, 1, 2 * plane);
+  if (argc > 1) {
+    // round 3: does a row pitch or a plane distance that is NOT a power of two change the ceiling? (2D column pass: rows 8 KiB
+    // apart, planes 2^31 B apart in the planar interface; the intermediate image set is the library's own and could be padded)
+    for (uint64_t pitch : {8192ull, 8192ull + 128, 8192ull + 256, 8192ull + 512, 8192ull + 2048}) {
+      for (uint64_t pad : {0ull, 4096ull + 256, 1ull << 20}) {
+        printf("plane distance 2^30 + %llu:", (unsigned long long)pad);
+        run<128>(in, out, pitch, plane + pad, 2, false);
+        printf("plane distance 2^30 + %llu:", (unsigned long long)pad);
+        run<256>(in, out, pitch, plane + pad, 2, false);
+      }
+    }
+    return 0;
+  }
   for (uint64_t pitch : {2048ull, 8192ull, 131072ull}) {
     for (int pair = 0; pair < 3; ++pair) {
       run<256>(in, out, pitch, plane, pair, false);

@@ -28,14 +28,15 @@ def candidates(n):
     0 = library default (2|8 at N = 4096); 32 = plain autosort chain; 524288 = 4-wave cooperative column workgroups;
     2097152 = unfused radix-16 + radix-2/4 tail; 1048576 = unstaged column stores; 16777216 = column plan instead of
     the single-pass kernel (2^13..2^15); 8388608 = no radix-512 column passes; 33554432 = no radix-1024 column passes; 134217728 = among the
-    splits with the fewest passes, the one with the most wide (radix-1024, then radix-512) passes."""
+    splits with the fewest passes, the one with the most wide (radix-1024, then radix-512) passes; 268435456 = a final radix-512
+    pass by the two-round kernel with two 4-wave workgroups per CU."""
     if n == 4096:
         return [16, 2, 10, 8, 1]
     if n < 8192:
         return [0, 32]
     if n <= 32768:
         return [0, 16777216, 16777216 | 8388608, 32]
-    return [0, 32, 524288, 2097152, 1048576, 8388608, 33554432, 8388608 | 33554432, 134217728]
+    return [0, 32, 524288, 2097152, 1048576, 8388608, 33554432, 8388608 | 33554432, 134217728, 268435456]
 
 
 def iters_candidates():
