@@ -111,8 +111,10 @@ typedef struct tfft_plan_opts {
                            passes; 33554432 = no radix-1024 column passes; 134217728 = among the splits with the
                            fewest passes, the one with the most radix-1024 (then radix-512) passes instead of the
                            measured default; 16777216 = N = 8192..32768 as a column plan instead of the single-pass kernel; 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
-                           268435456 = a final radix-512 pass by the two-round kernel that runs two 4-wave workgroups per
-                           CU (colfft512r.hpp) instead of the 8-wave single-round kernel.
+                           268435456 = a final radix-512 pass by the other of its two kernels: the two-round kernel
+                           (colfft512r.hpp: 128-column tiles, or 64-column tiles and two 4-wave workgroups per CU with bit
+                           524288) where the 8-wave single-round kernel is the default, and vice versa (default: two-round
+                           at row pitches of 256 and 512 columns).
                            Column passes: 131072 = per-wave kernel, 524288 = 4-wave cooperative workgroups,
                            262144 = no non-temporal accesses, 1048576 = 16-byte stores straight from registers,
                            4096 / 8192 = per-wave kernel with LDS-staged stores / hardware sin-cos twiddles.

@@ -26,26 +26,29 @@
 
 namespace colfft {
 
-constexpr int kWg512rThreads = 256;
-constexpr int kWg512rLdsBytes = kLdsTable + 2 * WgGeom<4>::kPlane;      // 80 KiB
+// W = 4: 64-column tiles (128-byte row segments), 80 KiB of LDS, two workgroups per CU. W = 8: 128-column tiles (256-byte row
+// segments, which this memory system moves 5 % faster: profiles/r3_stride_pad.txt), 144 KiB, one workgroup per CU.
+template <int W>
+constexpr int wg512r_lds_bytes() { return kLdsTable + 2 * WgGeom<W>::kPlane; }
 
-template <bool SC>
-__global__ __launch_bounds__(kWg512rThreads, 2) void colfft512r_wg_kernel(Args a) {
-  using G = WgGeom<4>;
-  constexpr int kPlane = G::kPlane, kRps = G::kRps, kCpr = G::kCpr;      // 32 KiB, 2 rows per 256-byte super-row, 8 chunks per row
+template <int W, bool SC, bool PF = (W == 8)>
+__global__ __launch_bounds__(64 * W, 2) void colfft512r_wg_kernel(Args a) {
+  using G = WgGeom<W>;
+  constexpr int kPlane = G::kPlane, kRps = G::kRps, kCpr = G::kCpr;      // W = 4: 32 KiB, 2 rows per 256-byte super-row, 8 chunks per row
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   h8 f_re = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32);
   h8 f_im = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32 + 16);
-  // the table slot: 16 KiB at the start of LDS, 4 KiB (four LDS-DMA instructions) per wave
+  // the table slot: 16 KiB at the start of LDS, 16 / W KiB (16 / W LDS-DMA instructions) per wave
+  constexpr int kTabPerWave = 16384 / W;
   const uint32_t tab_off = __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)lds)) + 4096 * wave);
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)lds)) + kTabPerWave * wave);
   auto dma_table = [&](int q) {
-    const uint8_t* src = a.tables + kOffG512 + 16384 * q + 4096 * wave + 16 * lane;
+    const uint8_t* src = a.tables + kOffG512 + 16384 * q + kTabPerWave * wave + 16 * lane;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kTabPerWave / 1024; ++i) {
       const uint8_t* gp = src + 1024 * i;
       const uint32_t d0 = tab_off + 1024 * i;
       uint32_t keep;
@@ -69,8 +72,8 @@ __global__ __launch_bounds__(kWg512rThreads, 2) void colfft512r_wg_kernel(Args a
   const uint8_t* const g_tab = lds + lane * 16;
   const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3, x = lane & 15;
   const int ihi = 4 * g + q4;
-  // image addressing exactly as colfft256_wg_kernel<.., W = 4>: row r, 16-byte chunk c lives in super-row r / 2 at slot
-  // ((r % 2) 8 + c) ^ 2 ((r >> 4) & 7)
+  // image addressing exactly as colfft256_wg_kernel<.., W>: row r, 16-byte chunk c lives in super-row r / kRps at slot
+  // ((r % kRps) kCpr + c) ^ 2 ((r >> 4) & 7)
   const uint8_t* tr_base[kRps];
 #pragma unroll
   for (int h = 0; h < kRps; ++h)
@@ -159,19 +162,59 @@ __global__ __launch_bounds__(kWg512rThreads, 2) void colfft512r_wg_kernel(Args a
            8 * ((gl & 1) ^ (xl >> 3));
   };
 
+  // PF: round 0 of the NEXT tile travels through registers instead: loaded behind barrier C (the image is busy until both
+  // read-outs are done), in flight under the read-outs and their stores, written to the image at the top of the next tile
+  // (what the 8-wave single-round kernel and colfft1024_wg_kernel do; 64 VGPRs that are free in that interval).
+  u4 ra_re[PF ? 8 : 1], ra_im[PF ? 8 : 1];
+  auto issue_loads = [&](uint32_t blk) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;
+    const uint64_t bidx = gc0 >> pshift;
+    const uint64_t mb = gc0 & (a.pitch - 1);
+    const uint16_t* const b_re = a.in_re + bidx * a.in_stride + mb;
+    const uint16_t* const b_im = a.in_im + bidx * a.in_stride + mb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t sr = 32 * wave + 4 * i + (lane >> 4);
+      const uint32_t v = (lane & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
+      const uint32_t row = 2 * (sr * kRps + v / kCpr);
+      const uint64_t off = (row * a.pitch + static_cast<uint64_t>(row >> a.in_seg_shift) * a.in_seg_gap + 8 * (v % kCpr)) * 2;
+      ra_re[PF ? i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(b_re) + off));
+      ra_im[PF ? i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(b_im) + off));
+    }
+  };
+  auto to_image = [&]() {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      *reinterpret_cast<u4*>(img + 8192 * wave + 1024 * i + 16 * lane) = ra_re[PF ? i : 0];
+      *reinterpret_cast<u4*>(img + kPlane + 8192 * wave + 1024 * i + 16 * lane) = ra_im[PF ? i : 0];
+    }
+  };
+
   Rotor rot(blockIdx.x, gridDim.x);                          // (block order: k4096::Rotor)
   dma_table(0);
-  if (rot.item() < total) dma_in(rot.item(), 0);
+  if (rot.item() < total) {
+    if (PF) issue_loads(rot.item());
+    else dma_in(rot.item(), 0);
+  }
 
   uint32_t sv_re[8][4], sv_im[8][4];                         // B_0, then D: [ka >> 1][2 (ka & 1) + {0, 1}] = columns {0,1}, {2,3} of tile ka
 
   for (uint32_t blk = rot.item(); blk < total; rot.advance(), blk = rot.item()) {
     const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;
-    const uint64_t bidx = gc0 >> pshift;                     // pitch >= 64: one batch entry per block
+    const uint64_t bidx = gc0 >> pshift;                     // pitch >= 16 W: one batch entry per block
     const uint64_t mb = gc0 & (a.pitch - 1);
 
     // ---------------- round 0: rows 2 m
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PF) {
+      to_image();                            // (the compiler waits for the register loads here)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();            // A0: image (round 0) and G_0 are in LDS
     {
       uint32_t pr[8][4], pi[8][4];
@@ -247,6 +290,8 @@ __global__ __launch_bounds__(kWg512rThreads, 2) void colfft512r_wg_kernel(Args a
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // C: S is complete in the image; the table slot is free
     dma_table(0);                            // G_0 of the next tile (lands long before it is needed)
+    // unconditional (the last tile re-reads itself): a conditional load keeps the old register contents alive through the loop
+    if (PF) issue_loads(rot.peek() < total ? rot.peek() : blk);
 
     // ---------------- read-out: rows k (S) and, through the same image, rows k + 256 (D)
     const uint64_t o_entry = (bidx >> a.out_sub_shift) * a.out_stride +
@@ -254,7 +299,7 @@ __global__ __launch_bounds__(kWg512rThreads, 2) void colfft512r_wg_kernel(Args a
     uint16_t* const o_re = a.out_re + o_entry;
     uint16_t* const o_im = a.out_im + o_entry;
     const uint32_t row_shift = a.ns_f_shift + a.out_row_shift;
-    const uint64_t restb = mb >> a.ns_f_shift;                 // shared by the block's 64 columns (ns_f % 64 == 0)
+    const uint64_t restb = mb >> a.ns_f_shift;                 // shared by the block's 16 W columns (ns_f % (16 W) == 0)
     const uint64_t obase = ((restb << 9) << a.ns_f_shift) + (mb - (restb << a.ns_f_shift));
     auto read_out = [&](const uint32_t krow0) {
       int lane = threadIdx.x & 63;
@@ -295,7 +340,7 @@ __global__ __launch_bounds__(kWg512rThreads, 2) void colfft512r_wg_kernel(Args a
     read_out(256);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // F: read out; the next tile's copy-in may overwrite the image
-    if (rot.peek() < total) dma_in(rot.peek(), 0);
+    if (!PF && rot.peek() < total) dma_in(rot.peek(), 0);
   }
   // (a table LDS-DMA of the last iteration may still be in flight: the workgroup must not give its LDS back before it lands)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -576,14 +576,24 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwFourStep>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
       else if (ps.tw_next)
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
-      else if (p->variant & 268435456) {
-        // variant bit 268435456: last pass of a plan / 2D column pass by the two-round kernel, two 4-wave workgroups per CU
-        // (colfft512r.hpp; measured 2-3 % behind the 8-wave kernel on MI355X, kept as a tuner alternative)
-        const uint32_t grid2 = pick_grid(blocks, 2 * p->num_cus, plan_iters(p->launch_iters, 1000000u));
-        if (ps.scale != 1.0f)            // TFFT_SCALE_ONCE: the single factor in fp32 at the combine
-          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<true>), dim3(grid2), dim3(colfft::kWg512rThreads), colfft::kWg512rLdsBytes, s, a);
+      else if (((a.pitch == 256 || a.pitch == 512) && a.ns_f % 128 == 0) != ((p->variant & 268435456) != 0)) {
+        // last pass of a plan / 2D column pass by the two-round kernel (colfft512r.hpp). A/B in one process on MI355X, 8 GiB per
+        // launch (profiles/r3_ab_colfft512r.txt): the 128-column two-round form is 2-4 % faster than the 8-wave single-round
+        // kernel at row pitches of 256 and 512 columns (2^18 = 512 x 512: 335 -> 342 Gsamples/s) and at 2048, 2-4 % slower at
+        // 128, 1024 and 4096 (the 2D column pass); the default follows that, variant bit 268435456 flips the choice
+        // 128-column tiles (256-byte row segments, one 8-wave workgroup per CU) where the geometry allows and variant bit
+        // 524288 does not ask for 4-wave workgroups; otherwise 64-column tiles, two 4-wave workgroups per CU
+        const bool w8 = !(p->variant & 524288) && a.pitch % 128 == 0 && a.ns_f % 128 == 0;
+        const uint32_t grid2 = pick_grid(w8 ? blocks / 2 : blocks, (w8 ? 1 : 2) * p->num_cus, plan_iters(p->launch_iters, 1000000u));
+        const bool sc = ps.scale != 1.0f;          // TFFT_SCALE_ONCE: the single factor in fp32 at the combine
+        if (w8 && sc)
+          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, true>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a);
+        else if (w8)
+          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, false>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a);
+        else if (sc)
+          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<4, true>), dim3(grid2), dim3(256), colfft::wg512r_lds_bytes<4>(), s, a);
         else
-          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<false>), dim3(grid2), dim3(colfft::kWg512rThreads), colfft::kWg512rLdsBytes, s, a);
+          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<4, false>), dim3(grid2), dim3(256), colfft::wg512r_lds_bytes<4>(), s, a);
       } else if (ps.scale != 1.0f)       // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
       else

@@ -95,3 +95,56 @@ def test_reference_api_uses_the_tuner_line_of_the_nearest_batch(tf, tmp_path):
         o = out.reshape(batch, 2, 4096).astype(np.float64)
         got = o[:, 0] + 1j * o[:, 1]
         assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL
+
+
+@pytest.mark.parametrize("inner,batch", [(64, 3), (128, 2), (256, 5), (4096, 2)])
+@pytest.mark.parametrize("extra", [0, 524288])
+def test_two_round_radix512_kernel_strided_axis(tf, inner, batch, extra):
+    """colfft512r.hpp (variant bit 268435456): 128-column tiles / 8 waves where the geometry allows, 64-column tiles / 4 waves
+    otherwise or with bit 524288; against numpy's fp64 FFT and within an ulp or so of the 8-wave single-round kernel."""
+    import torch
+
+    n = 512
+    rng = np.random.default_rng(inner + batch)
+    re = rng.uniform(-1, 1, (batch, n, inner)).astype(np.float16)
+    im = rng.uniform(-1, 1, (batch, n, inner)).astype(np.float16)
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
+    exact = np.fft.fft(re.astype(np.float64) + 1j * im.astype(np.float64), axis=1) / n
+    got = {}
+    for v in (67108864, 67108864 | 268435456 | extra):
+        for scale in ("sequential", "once"):
+            out = torch.full_like(dev, float("nan"))
+            plan = tf.TfftPlan(n, batch, 0, inner=inner, variant=v, scale=scale)
+            assert plan.num_launches == 1
+            plan.exec(dev, dev[n * inner:], out, out[n * inner:])
+            torch.cuda.synchronize()
+            o = out.cpu().numpy().reshape(batch, 2, n, inner).astype(np.float64)
+            z = o[:, 0] + 1j * o[:, 1]
+            assert np.linalg.norm(z - exact) / np.linalg.norm(exact) <= REL_L2_TOL, (v, scale)
+            got[(v, scale)] = z
+    a, b = got[(67108864, "sequential")], got[(67108864 | 268435456 | extra, "sequential")]
+    assert np.abs(a - b).max() <= 2.0 ** -10 * np.abs(exact).max()       # one rounding apart, not two algorithms apart
+
+
+@pytest.mark.parametrize("variant", [268435456, 268435456 | 524288])
+def test_two_round_radix512_kernel_as_last_pass_of_2pow18(tf, orc, variant):
+    import torch
+
+    n, batch = 1 << 18, 6
+    assert tf.plan_describe(n) == "col:512+tw col:512"
+    x = torch.empty(batch * 2 * n, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x, x[n:], n, batch, seed=18)
+    for scale in ("sequential", "none", "once"):
+        y = torch.full_like(x, float("nan"))
+        xin = x if scale != "none" else (x * (1.0 / 64)).half()
+        tf.TfftPlan(n, batch, 0, preserve_input=True, variant=variant, scale=scale).exec(xin, xin[n:], y, y[n:])
+        torch.cuda.synchronize()
+        for b in (0, batch - 1):
+            re, im = orc.synth_uniform(n, 1, b, 18)
+            if scale == "none":
+                re, im = (re * np.float16(1.0 / 64)).astype(np.float16), (im * np.float16(1.0 / 64)).astype(np.float16)
+            e_re, e_im = orc.dft64(re, im)
+            exact = (e_re[0] + 1j * e_im[0]) * (n if scale == "none" else 1)
+            o = y[b * 2 * n:(b + 1) * 2 * n].cpu().numpy().astype(np.float64)
+            got = o[:n] + 1j * o[n:]
+            assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL, (variant, scale, b)
