@@ -296,7 +296,8 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
 void tfft_dist_plan_destroy(tfft_dist_plan* plan);
 int tfft_dist_plan_geometry(const tfft_dist_plan* plan, tfft_dist_geometry* out);
 /* The exchange buffers (N / world halves each; chunk q at + q * chunk). set_buffers replaces them by caller-owned device
- * memory (16-byte aligned), e.g. tensors a framework's own collective can send. */
+ * memory (16-byte aligned, send and receive distinct), e.g. tensors a framework's own collective can send. With one rank and
+ * no TFFT_DIST_SELF_VIA_COMM nothing is exchanged: the receive buffers ARE the send buffers and the recv arguments are ignored. */
 int tfft_dist_plan_buffers(const tfft_dist_plan* plan, void** send_re, void** send_im, void** recv_re, void** recv_im);
 int tfft_dist_plan_set_buffers(tfft_dist_plan* plan, void* send_re, void* send_im, void* recv_re, void* recv_im);
 int tfft_dist_exec_pre(const tfft_dist_plan* plan, const void* in_re, const void* in_im, void* stream);

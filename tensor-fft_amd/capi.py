@@ -443,6 +443,8 @@ class DistComm:
         if h:
             self._h = None
             self._lib.tfft_dist_comm_destroy(h)
+    # (no __del__: destroying a communicator from the garbage collector at interpreter shutdown, after the HIP runtime's own
+    # teardown has begun, can hang; a communicator that is never closed is reclaimed with the process)
 
 
 class DistPlan:

@@ -362,8 +362,12 @@ int tfft_dist_plan_set_buffers(tfft_dist_plan* p, void* send_re, void* send_im, 
     return fail(TFFT_ERR_ARG, "buffers must be 16-byte aligned");
   p->send_re = static_cast<_Float16*>(send_re);
   p->send_im = static_cast<_Float16*>(send_im);
-  p->recv_re = static_cast<_Float16*>(recv_re);
-  p->recv_im = static_cast<_Float16*>(recv_im);
+  // one rank and no collective: nothing moves between the phases, the row transforms read what the column pass wrote
+  const bool two_sided = p->g.world > 1 || p->self_via_comm;
+  p->recv_re = two_sided ? static_cast<_Float16*>(recv_re) : p->send_re;
+  p->recv_im = two_sided ? static_cast<_Float16*>(recv_im) : p->send_im;
+  if (two_sided && (recv_re == send_re || recv_im == send_im || recv_re == send_im || recv_im == send_re))
+    return fail(TFFT_ERR_ARG, "send and receive buffers must be distinct");
   return TFFT_OK;
 }
 
