@@ -10,7 +10,7 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 template <bool NT>
 __global__ __launch_bounds__(512) void k(const uint16_t* in_re, const uint16_t* in_im, uint16_t* out_re, uint16_t* out_im,
-                                        uint32_t iterations, int adj_in, int adj_out) {
+                                        uint32_t iterations, int adj_in, int adj_out, int ilv_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t rnd = 0, pos = blockIdx.x;
   for (uint32_t it = blockIdx.x; it < iterations; ++rnd, pos = (pos + 1 == gridDim.x) ? 0 : pos + 1, it = rnd * gridDim.x + pos) {
@@ -20,8 +20,10 @@ __global__ __launch_bounds__(512) void k(const uint16_t* in_re, const uint16_t* 
     const uint64_t row_out = adj_out ? (8u * r0 + wave) : (r0 + 512u * wave);
     const uint16_t* sr = in_re + img + row_in * 4096;
     const uint16_t* si = in_im + img + row_in * 4096;
-    uint16_t* dr = out_re + img + row_out * 4096;
-    uint16_t* di = out_im + img + row_out * 4096;
+    // ilv_out: the output image keeps [RE row | IM row] pairs (row pitch 2 x 4096 halves): what the library's own intermediate
+    // image set could look like
+    uint16_t* dr = ilv_out ? out_re + 2 * img + row_out * 8192 : out_re + img + row_out * 4096;
+    uint16_t* di = ilv_out ? dr + 4096 : out_im + img + row_out * 4096;
     u4 vr[8], vi[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -55,13 +57,15 @@ int main() {
   const uint32_t iterations = images * 512;
   for (int nt = 0; nt < 2; ++nt)
     for (int adj_in = 0; adj_in < 2; ++adj_in)
-      for (int adj_out = 0; adj_out < 2; ++adj_out) {
+      for (int mode = 0; mode < 3; ++mode) {
+        const int adj_out = mode == 1, ilv_out = mode == 2;
+        if (adj_in && ilv_out) continue;
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
         hipEventCreate(&e1);
         auto launch = [&] {
-          if (nt) hipLaunchKernelGGL(k<true>, dim3(256), dim3(512), 0, 0, in, in + plane, out, out + plane, iterations, adj_in, adj_out);
-          else hipLaunchKernelGGL(k<false>, dim3(256), dim3(512), 0, 0, in, in + plane, out, out + plane, iterations, adj_in, adj_out);
+          if (nt) hipLaunchKernelGGL(k<true>, dim3(256), dim3(512), 0, 0, in, in + plane, out, out + plane, iterations, adj_in, adj_out, ilv_out);
+          else hipLaunchKernelGGL(k<false>, dim3(256), dim3(512), 0, 0, in, in + plane, out, out + plane, iterations, adj_in, adj_out, ilv_out);
         };
         for (int w = 0; w < 20; ++w) launch();
         hipEventRecord(e0);
@@ -73,7 +77,7 @@ int main() {
         hipEventElapsedTime(&ms, e0, e1);
         ms /= reps;
         printf("%s accesses, input rows %s, output rows %s: %8.1f us  %6.0f GB/s\n", nt ? "non-temporal" : "plain       ",
-               adj_in ? "adjacent    " : "4 MiB apart ", adj_out ? "adjacent    " : "4 MiB apart ", ms * 1e3, 4.0 * plane * 2 / ms * 1e-6);
+               adj_in ? "adjacent    " : "4 MiB apart ", ilv_out ? "[RE|IM] rows, 8 MiB apart" : (adj_out ? "adjacent    " : "4 MiB apart "), ms * 1e3, 4.0 * plane * 2 / ms * 1e-6);
       }
   return 0;
 }

@@ -41,7 +41,7 @@ def main():
     t_last = time.time()
     kinds = {}
     while time.time() < t_end:
-        kind = str(rng.choice(["plain", "plain", "strided", "transposed", "fourstep", "scale", "variant"]))
+        kind = str(rng.choice(["plain", "plain", "strided", "transposed", "fourstep", "scale", "variant", "launch"]))
         kw = {}
         inner = 1
         if kind == "strided":
@@ -64,6 +64,11 @@ def main():
         elif kind == "variant":
             lg = int(rng.integers(8, 23))
             kw["variant"] = int(rng.choice(tuner.candidates(1 << lg)))
+        elif kind == "launch":                      # launch shapes (round 3): any rounds-per-workgroup value, any length
+            lg = int(rng.integers(8, 23))
+            kw["launch_iters"] = int(rng.choice([1, 2, 3, 4, 7, 65535]))
+            if rng.integers(0, 2):
+                kw["variant"] = int(rng.choice(tuner.candidates(1 << lg)))
         else:
             lg = int(rng.integers(1, 23))
         n = 1 << lg

@@ -51,11 +51,11 @@ __global__ __launch_bounds__(512) void k(const uint8_t* in, uint8_t* out, uint64
 }
 
 template <int SEG>
-void run(const uint8_t* in, uint8_t* out, uint64_t pitch, uint64_t plane_bytes, int pair, bool nt_off) {
+void run(const uint8_t* in, uint8_t* out, uint64_t pitch, uint64_t plane_bytes, int pair, bool nt_off, uint64_t row_bytes = 0) {
   constexpr int ROWS = 65536 / SEG;
   const uint64_t entry = ROWS * pitch;                   // one transform: ROWS rows of pitch bytes
-  const uint32_t bpe = static_cast<uint32_t>(pitch / SEG);
-  const uint32_t entries = static_cast<uint32_t>((1ull << 30) / entry);
+  const uint32_t bpe = static_cast<uint32_t>((row_bytes ? row_bytes : pitch) / SEG);
+  const uint32_t entries = static_cast<uint32_t>((1ull << 30) / (row_bytes ? ROWS * row_bytes : entry));
   const uint32_t total = entries * bpe;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k<SEG>, dim3(256), dim3(512), 0, 0, in, out, pitch, bpe, total, entry, plane_bytes, pair);
@@ -85,6 +85,11 @@ int main(int argc, char** argv) {
         run<256>(in, out, pitch, plane + pad, 2, false);
       }
     }
+    // the same tiles read from / written to an image set whose rows are [RE row | IM row] pairs: planes 8 KiB apart, row pitch 16 KiB
+    printf("[RE|IM] row pairs (plane distance 8192 B, row pitch 16384 B):");
+    run<128>(in, out, 16384, 8192, 2, false, 8192);
+    printf("[RE|IM] row pairs (plane distance 8192 B, row pitch 16384 B):");
+    run<256>(in, out, 16384, 8192, 2, false, 8192);
     return 0;
   }
   for (uint64_t pitch : {2048ull, 8192ull, 131072ull}) {
