@@ -148,3 +148,16 @@ def test_two_round_radix512_kernel_as_last_pass_of_2pow18(tf, orc, variant):
             o = y[b * 2 * n:(b + 1) * 2 * n].cpu().numpy().astype(np.float64)
             got = o[:n] + 1j * o[n:]
             assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL, (variant, scale, b)
+
+
+def test_cxx_unit_test_of_the_reference_protocol(tf):
+    """examples/unit_test.cpp: the reference's UnitTest.cu (2^8 .. 2^20, 10 signals per length, 20 harmonics, thresholds
+    1e-3 / 1e-2 / 0.5) written against include/tensor_fft.hpp, comparison data from hipFFT Z2Z as the reference's comes
+    from cuFFT Z2Z."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "examples", "unit_test")
+    r = subprocess.run(["timeout", "-k", "10", "600", exe, "20"], capture_output=True, text=True)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and "All tests passed!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("Testing fft_length") == 13
