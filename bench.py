@@ -319,7 +319,7 @@ def self_launch(n_ranks, script, script_args, nproc_visible=None):
     return rc
 
 
-def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20):
+def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm=False):
     """BASELINE configs[4b]: ONE transform of N = 2^26 spread over the `world` GPUs, four-step with a single RCCL exchange
     (tfft_dist_exec: column pass -> ncclSend / ncclRecv group -> row transforms, all on one stream). Every rank calls this;
     returns the report (identical on all ranks). Checked: Parseval over all ranks and four spectrum bins per rank against a
@@ -333,7 +333,8 @@ def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20):
     # over the torch process group, and the report says so.
     f, why = None, ""
     try:
-        f = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="rccl" if world > 1 else None)
+        f = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="rccl" if (world > 1 or self_via_comm) else None,
+                             self_via_comm=self_via_comm)
     except Exception as e:      # noqa: BLE001
         why = f"{type(e).__name__}: {e}"
     if world > 1:
@@ -433,6 +434,9 @@ def main():
                          "configs[4a] at N > 1 GPUs)")
     ap.add_argument("--with-dist", action="store_true",
                     help="also run the BASELINE configs[4b] entry (N = 2^26 through tfft_dist_*) when there is only one rank")
+    ap.add_argument("--dist-self-via-comm", action="store_true",
+                    help="rehearsal aid for a one-GPU box (with --with-dist): the configs[4b] entry creates its RCCL communicator and "
+                         "routes the own chunk through ncclSend / ncclRecv, next to the torch process group's own communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra measurements of the other BASELINE configs (reported under 'other_configs')")
@@ -615,7 +619,7 @@ def main():
         x = y = None
         torch.cuda.empty_cache()
         try:
-            rep = dist_2pow26(torch, tf, dist, rank, world, local_rank)
+            rep = dist_2pow26(torch, tf, dist, rank, world, local_rank, self_via_comm=args.dist_self_via_comm)
         except Exception as e:      # noqa: BLE001  (the headline line must not depend on this entry)
             rep = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
