@@ -634,7 +634,12 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   // CU up to a pitch of 16384: 2^20 x 1024 221.6 -> 228.9 Gsamples/s, 2^22 215.5 -> 220.1; beyond that the 128-byte
   // segments lose more than the overlap gives: 2^24 194.6 -> 170.8)
   static const uint32_t wg4_max_pitch_regs = env_iters("TFFT_WG4_MAX_PITCH_INREGS", 16384);
-  const uint32_t wg4_max_pitch = (a.ns_f == 1) ? wg4_max_pitch_lanes : wg4_max_pitch_regs;
+  // Round 3, today's kernels (rotated work distribution, conflict-free staging), W = 4 against W = 8 on one box
+  // (profiles/r3_ab_w4_w8.txt): the plain and next-pass-twiddle forms prefer 8-wave workgroups (256-byte segments) from a pitch
+  // of 512 columns on: +4 % at 512 (last pass of 2^17: 345 -> 358 Gsamples/s), +6 % at 1024, +10 % at 4096, +4 % at 16384; at 256
+  // the two 4-wave workgroups per CU still win by 2-3 %. The four-step form is within 1 % either way and keeps its threshold.
+  const uint32_t wg4_regs = p->tw4_modulus ? wg4_max_pitch_regs : std::min<uint32_t>(wg4_max_pitch_regs, 256u);
+  const uint32_t wg4_max_pitch = (a.ns_f == 1) ? wg4_max_pitch_lanes : wg4_regs;
   // ... also when 8-wave workgroups would leave CUs idle (single long transforms: 2^20 x 1 is 32 blocks of 128 columns)
   const bool few_blocks = entries * a.pitch / 128 < static_cast<uint64_t>(p->num_cus);
   if (wg_allowed && wg4_ok && ((p->variant & 524288) || !wg8_ok || a.pitch <= wg4_max_pitch || few_blocks))
