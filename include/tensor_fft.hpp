@@ -29,6 +29,7 @@
 #include <optional>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -168,6 +169,36 @@ inline std::optional<std::string> staged(int rc) {
   if (rc == TFFT_OK) return std::nullopt;
   return std::string(tfft_last_error());
 }
+// Host <-> device copies of the handlers. Default: ONE blocking hipMemcpy, exactly the reference's cudaMemcpy
+// (src/base/DataHandler.h:45-70,116-153): ROCm 7.2's pageable path already pipelines through pinned buffers and measured
+// 55.6 / 55.8 GB/s on MI355X against 53.7 / 53.3 for the library's own pinned ring (tfft_copy_h2d / _d2h; 1.07 GB,
+// profiles/r3_bench_batched_cxx.txt), both ~0.85 of PCIe Gen5 x16. SetStagedCopies(true) selects the ring (per-device
+// locks: host threads that feed different devices overlap).
+inline bool& staged_copies_flag() {
+  static bool on = false;
+  return on;
+}
+inline std::optional<std::string> copy_h2d(void* dst, const void* src, size_t bytes) {
+  if (staged_copies_flag()) return staged(tfft_copy_h2d(dst, src, bytes));
+  return hip_status(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+}
+inline std::optional<std::string> copy_d2h(void* dst, const void* src, size_t bytes) {
+  if (staged_copies_flag()) return staged(tfft_copy_d2h(dst, src, bytes));
+  return hip_status(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+}
+// fn(i) for every device slot i at once, one host thread per device: the transfers of all devices are in flight together
+// (each device has its own PCIe link; one thread issuing blocking copies device after device would use one link at a time)
+template <typename Fn>
+inline std::optional<std::string> for_each_device_parallel(size_t n, Fn fn) {
+  std::vector<std::optional<std::string>> err(n);
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < n; ++i) th.emplace_back([&, i] { err[i] = fn(i); });
+  if (n) err[0] = fn(0);
+  for (auto& t : th) t.join();
+  for (auto& e : err)
+    if (e) return e;
+  return std::nullopt;
+}
 
 // One execution plan per (N, batch, device, variant), kept for the life of the process so that
 // ComputeFFT stays a pure launch, like the reference's. The cache is shared by all host threads (a tfft_plan is
@@ -192,7 +223,7 @@ inline tfft_plan* exec_plan(uint64_t n, uint64_t batch, int variant, std::string
   std::lock_guard<std::mutex> guard(lock);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
-  tfft_plan_opts opts{};
+  tfft_plan_opts opts = TFFT_PLAN_OPTS_INIT;
   opts.variant = variant;
   opts.launch_iters = static_cast<uint32_t>(launch_iters);
   tfft_plan* p = nullptr;
@@ -225,6 +256,10 @@ inline std::pair<int, int> tuned_for_batch(const PlanT& plan, uint64_t batch) {
 }
 }  // namespace tfft_detail
 
+// Not in the reference: selects the library's pinned staging ring (tfft_copy_h2d / _d2h) for the handlers' host copies
+// instead of one blocking hipMemcpy (see tfft_detail::copy_h2d for the measurement behind the default).
+inline void SetStagedCopies(bool on) { tfft_detail::staged_copies_flag() = on; }
+
 // Not in the reference (its plans own no device memory): destroys the execution plans ComputeFFT has cached, with their
 // constant tables and workspaces (a 2^26 plan holds 512 MiB). Call with no ComputeFFT in flight; later calls re-create.
 inline void ReleaseComputeFFTPlans() {
@@ -256,15 +291,14 @@ class DataHandler {
 
   std::optional<std::string> PeakAtLastError() { return tfft_detail::peek(); }
 
-  // (pageable host memory travels through the library's pinned staging ring, tfft_copy_h2d / _d2h: chunked hipMemcpyAsync
-  // overlapped with the host-side copies; the reference: one blocking cudaMemcpy, DataHandler.h:45-70)
+  // one blocking copy like the reference's (DataHandler.h:45-70): ordered behind whatever ComputeFFT has queued on the device
   std::optional<std::string> CopyDataHostToDevice(__half* data) {
-    return tfft_detail::staged(tfft_copy_h2d(dptr_input_RE_, data, 2 * static_cast<size_t>(fft_length_) * sizeof(__half)));
+    return tfft_detail::copy_h2d(dptr_input_RE_, data, 2 * static_cast<size_t>(fft_length_) * sizeof(__half));
   }
 
   std::optional<std::string> CopyResultsDeviceToHost(__half* data, bool results_in_results) {
     const __half* src = results_in_results ? dptr_results_RE_ : dptr_input_RE_;
-    return tfft_detail::staged(tfft_copy_d2h(data, src, 2 * static_cast<size_t>(fft_length_) * sizeof(__half)));
+    return tfft_detail::copy_d2h(data, src, 2 * static_cast<size_t>(fft_length_) * sizeof(__half));
   }
 
   Integer fft_length_;
@@ -299,15 +333,14 @@ class DataBatchHandler {
 
   std::optional<std::string> PeakAtLastError() { return tfft_detail::peek(); }
 
-  // pinned, chunked, overlapped (tfft_copy_h2d / _d2h); the reference: one blocking cudaMemcpy, DataHandler.h:116-153
+  // one blocking copy, the reference's: DataHandler.h:116-153 (tfft_detail::copy_h2d)
   std::optional<std::string> CopyDataHostToDevice(__half* data) {
-    return tfft_detail::staged(tfft_copy_h2d(dptr_input_RE_[0], data,
-                                             static_cast<size_t>(amount_of_ffts_) * 2 * fft_length_ * sizeof(__half)));
+    return tfft_detail::copy_h2d(dptr_input_RE_[0], data, static_cast<size_t>(amount_of_ffts_) * 2 * fft_length_ * sizeof(__half));
   }
 
   std::optional<std::string> CopyResultsDeviceToHost(__half* data, bool results_in_results) {
     const __half* src = results_in_results ? dptr_results_RE_[0] : dptr_input_RE_[0];
-    return tfft_detail::staged(tfft_copy_d2h(data, src, static_cast<size_t>(amount_of_ffts_) * 2 * fft_length_ * sizeof(__half)));
+    return tfft_detail::copy_d2h(data, src, static_cast<size_t>(amount_of_ffts_) * 2 * fft_length_ * sizeof(__half));
   }
 
   Integer fft_length_;
@@ -405,27 +438,24 @@ class DataBatchHandlerMultiGPU {
   }
 
   // data: the whole batch, [fft_i RE | fft_i IM] blocks in order (DataBatchHandler's layout)
+  // (all devices' slices in flight at once, one host thread per device: every GPU has its own PCIe link)
   std::optional<std::string> CopyDataHostToDevice(__half* data) {
-    for (size_t i = 0; i < device_ids_.size(); ++i) {
-      if (!count_[i]) continue;
-      (void)hipSetDevice(device_ids_[i]);
-      if (auto e = tfft_detail::hip_status(hipMemcpy(input(static_cast<int>(i)), data + static_cast<size_t>(first_[i]) * 2 * fft_length_,
-                                                     static_cast<size_t>(count_[i]) * 2 * fft_length_ * sizeof(__half), hipMemcpyHostToDevice)))
-        return e;
-    }
-    return std::nullopt;
+    return tfft_detail::for_each_device_parallel(device_ids_.size(), [&](size_t i) -> std::optional<std::string> {
+      if (!count_[i]) return std::nullopt;
+      if (hipSetDevice(device_ids_[i]) != hipSuccess) return std::string("hipSetDevice failed");
+      return tfft_detail::copy_h2d(input(static_cast<int>(i)), data + static_cast<size_t>(first_[i]) * 2 * fft_length_,
+                                   static_cast<size_t>(count_[i]) * 2 * fft_length_ * sizeof(__half));
+    });
   }
 
   std::optional<std::string> CopyResultsDeviceToHost(__half* data, bool results_in_results) {
-    for (size_t i = 0; i < device_ids_.size(); ++i) {
-      if (!count_[i]) continue;
-      (void)hipSetDevice(device_ids_[i]);
+    return tfft_detail::for_each_device_parallel(device_ids_.size(), [&](size_t i) -> std::optional<std::string> {
+      if (!count_[i]) return std::nullopt;
+      if (hipSetDevice(device_ids_[i]) != hipSuccess) return std::string("hipSetDevice failed");
       const __half* src = results_in_results ? results(static_cast<int>(i)) : input(static_cast<int>(i));
-      if (auto e = tfft_detail::hip_status(hipMemcpy(data + static_cast<size_t>(first_[i]) * 2 * fft_length_, src,
-                                                     static_cast<size_t>(count_[i]) * 2 * fft_length_ * sizeof(__half), hipMemcpyDeviceToHost)))
-        return e;
-    }
-    return std::nullopt;
+      return tfft_detail::copy_d2h(data + static_cast<size_t>(first_[i]) * 2 * fft_length_, src,
+                                   static_cast<size_t>(count_[i]) * 2 * fft_length_ * sizeof(__half));
+    });
   }
 
   Integer fft_length_;
@@ -563,7 +593,7 @@ class DataHandlerMultiGPU {
   std::vector<tfft_dist_plan*> plans_;
   std::vector<void*> comms_;
   std::vector<__half*> dptr_data_;
-  tfft_dist_geometry geometry_{};
+  tfft_dist_geometry geometry_ = TFFT_DIST_GEOMETRY_INIT;
   std::string error_;
 };
 

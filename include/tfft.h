@@ -94,6 +94,15 @@ int tfft_max_no_optin_shared_mem(int device_id);
  * must not overlap in time (same stream, or one plan per stream). Single-pass plans
  * (N <= 32768 with a contiguous axis) have no such restriction. */
 typedef struct tfft_plan_opts {
+  uint32_t struct_size; /* sizeof(tfft_plan_opts) AS THE CALLER WAS COMPILED (TFFT_PLAN_OPTS_INIT / tfft_plan_opts_init set it).
+                           The struct grows by appending fields (48 bytes: through output_order; 64: + fourstep_n,
+                           fourstep_col0; 72: + launch_iters and input_order, which share one 8-byte slot); the library reads
+                           exactly struct_size bytes and takes every field beyond them as 0, so a
+                           caller built against an older header keeps working against a newer library. Accepted: the size of
+                           every released layout (tfft_plan_opts_known_size); 0 and anything else is refused with TFFT_ERR_ARG
+                           instead of being read past its end. The reference's boundary is source level (default arguments of
+                           CreatePlan, src/base/Plan.h:77-82) and never had this problem; a C ABI does. */
+  uint32_t reserved_;   /* must be 0 */
   uint64_t in_batch_stride;
   uint64_t out_batch_stride;
   uint64_t inner;       /* 0/1: plain batched transforms. C >= 8 (power of two): transform along a strided
@@ -140,8 +149,18 @@ typedef struct tfft_plan_opts {
                            dispatcher refilling CUs as they drain (at least one workgroup per CU while there is that much
                            work); TFFT_LAUNCH_PERSISTENT: one workgroup per CU for the whole batch. Never changes results (the
                            kernels stride over the batch): the best shape at batch 65536 is not the best at batch 64. */
+  int input_order;      /* TFFT_ORDER_* below; 0 = natural order. TFFT_ORDER_TRANSPOSED: the input is the [N1][N2] matrix
+                           in[k1 * N2 + k2] = x[k1 + N1 * k2] that a TRANSPOSED-output plan of the same length leaves behind
+                           (see there), and the result is in natural order: two passes over HBM for 2^16 <= N <= 2^24 */
 } tfft_plan_opts;
 enum { TFFT_LAUNCH_PERSISTENT = 65535 };
+/* Zero-initialised options that carry the compile-time size: `tfft_plan_opts o = TFFT_PLAN_OPTS_INIT;` */
+#define TFFT_PLAN_OPTS_INIT {(uint32_t)sizeof(tfft_plan_opts)}
+/* The same at run time, for bindings that build the struct by hand (cgo, ctypes, JNI): zeroes `bytes` bytes at opts and
+ * writes struct_size = bytes. TFFT_ERR_ARG when `bytes` is not the size of a released layout. */
+int tfft_plan_opts_init(tfft_plan_opts* opts, size_t bytes);
+/* Host only: 1 if `bytes` is the size of a layout of tfft_plan_opts this library knows (48, 64 or 72, see struct_size), else 0. */
+int tfft_plan_opts_known_size(size_t bytes);
 
 /* tfft_plan_opts.scale — where the 1/N goes. The reference ships "sequential scaling" and keeps the other two as
  * commented-out variants (src/base/TensorFFT256.cu:163-177 "For unscaled results" / "For scaling in one step",
@@ -262,6 +281,10 @@ int tfft_permute_twiddle(const void* in_re, const void* in_im, void* out_re, voi
 typedef struct tfft_dist_plan tfft_dist_plan;
 
 typedef struct tfft_dist_geometry {
+  uint32_t struct_size; /* IN: sizeof(tfft_dist_geometry) as the caller was compiled (TFFT_DIST_GEOMETRY_INIT). The library fills
+                           at most that many bytes, so an older, shorter struct is never written past its end; 0 or a size
+                           below the round-4 layout is refused (TFFT_ERR_ARG) */
+  uint32_t reserved_;
   uint64_t n, n1, n2;  /* N = N1 N2 */
   uint64_t cols;       /* C = N2 / world: columns per rank in the column pass */
   uint64_t rows;       /* K = N1 / world: rows per rank in the row pass */
@@ -271,8 +294,10 @@ typedef struct tfft_dist_geometry {
   int reorder;         /* 1: a re-order pass [p'][k][c] -> [k][p' C + c] runs in front of the row transforms; 0: they read the segments in place */
   int local_passes;    /* passes over this rank's N / world samples per transform */
 } tfft_dist_geometry;
+#define TFFT_DIST_GEOMETRY_INIT {(uint32_t)sizeof(tfft_dist_geometry)}
 
-/* Host only: the split tfft_dist_plan_create would choose (TFFT_ERR_ARG when N < 256 * 64 * world). */
+/* Host only: the split tfft_dist_plan_create would choose (TFFT_ERR_ARG when N < 256 * 64 * world). out->struct_size must
+ * be set by the caller (see there). */
 int tfft_dist_geometry_query(uint64_t n, int world, int rank, tfft_dist_geometry* out);
 
 /* RCCL plumbing for callers that do not bind RCCL themselves. id: TFFT_DIST_ID_BYTES bytes (an ncclUniqueId) made on one rank,
@@ -282,8 +307,11 @@ int tfft_dist_unique_id(void* id128);
 int tfft_dist_comm_create(int world, int rank, const void* id128, int device_id, void** comm);
 int tfft_dist_comm_create_all(int ndev, const int* devices, void** comms);   /* one process, ndev devices (ncclCommInitAll) */
 int tfft_dist_comm_destroy(void* comm);
+int tfft_dist_comm_info(void* comm, int* count, int* rank);   /* ncclCommCount / ncclCommUserRank; either pointer may be NULL */
 int tfft_dist_group_start(void);
 int tfft_dist_group_end(void);
+/* ncclGetVersion of the RCCL this process has bound (e.g. 22703 = 2.27.3), for run reports */
+int tfft_dist_rccl_version(int* version);
 
 /* comm: this rank's ncclComm_t (the caller's own or from tfft_dist_comm_create), or NULL: then tfft_dist_exec_exchange is
  * unavailable and the caller moves the chunks itself between _pre and _post (tfft_dist_plan_buffers; how the tests run
@@ -291,12 +319,16 @@ int tfft_dist_group_end(void);
 /* flags: TFFT_DIST_SELF_VIA_COMM = the rank's own chunk travels through ncclSend / ncclRecv (to itself, inside the same group)
  * instead of a device-to-device copy. No use in production; it lets a box with ONE GPU run the RCCL path of the exchange
  * (world = 1: kernel -> collective -> kernel on one stream). */
-enum { TFFT_DIST_SELF_VIA_COMM = 1 };
+/*        TFFT_DIST_CALLER_BUFFERS = the plan allocates NO exchange buffers of its own (4 planes of N / world halves: 512 MiB at
+ * N = 2^26 on one rank): the caller hands its own in with tfft_dist_plan_set_buffers before the first execution, e.g. tensors that
+ * a framework's own collective can send. */
+enum { TFFT_DIST_SELF_VIA_COMM = 1, TFFT_DIST_CALLER_BUFFERS = 2 };
 int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* comm, int flags, tfft_dist_plan** out);
 void tfft_dist_plan_destroy(tfft_dist_plan* plan);
 int tfft_dist_plan_geometry(const tfft_dist_plan* plan, tfft_dist_geometry* out);
 /* The exchange buffers (N / world halves each; chunk q at + q * chunk). set_buffers replaces them by caller-owned device
- * memory (16-byte aligned, send and receive distinct), e.g. tensors a framework's own collective can send. With one rank and
+ * memory (16-byte aligned; the four ranges must not overlap: checked as ranges of N / world halves, and nothing is changed
+ * when the call fails), e.g. tensors a framework's own collective can send. With one rank and
  * no TFFT_DIST_SELF_VIA_COMM nothing is exchanged: the receive buffers ARE the send buffers and the recv arguments are ignored. */
 int tfft_dist_plan_buffers(const tfft_dist_plan* plan, void** send_re, void** send_im, void** recv_re, void** recv_im);
 int tfft_dist_plan_set_buffers(tfft_dist_plan* plan, void* send_re, void* send_im, void* recv_re, void* recv_im);

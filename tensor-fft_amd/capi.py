@@ -24,7 +24,8 @@ SYMBOLS = [
     "tfft_dist_comm_destroy", "tfft_dist_group_start", "tfft_dist_group_end", "tfft_dist_plan_create",
     "tfft_dist_plan_destroy", "tfft_dist_plan_geometry", "tfft_dist_plan_buffers", "tfft_dist_plan_set_buffers",
     "tfft_dist_exec_pre", "tfft_dist_exec_exchange", "tfft_dist_exec_post", "tfft_dist_exec",
-    "tfft_copy_h2d", "tfft_copy_d2h", "tfft_plan_prepare",
+    "tfft_copy_h2d", "tfft_copy_d2h", "tfft_plan_prepare", "tfft_plan_opts_init", "tfft_plan_opts_known_size",
+    "tfft_dist_rccl_version", "tfft_dist_comm_info",
 ]
 
 LAUNCH_PERSISTENT = 65535                                     # tfft_plan_opts.launch_iters
@@ -62,7 +63,10 @@ class RefPlanStruct(ctypes.Structure):
 
 
 class PlanOpts(ctypes.Structure):
+    """tfft_plan_opts (include/tfft.h): struct_size first, the library reads exactly that many bytes."""
     _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("reserved_", ctypes.c_uint32),
         ("in_batch_stride", ctypes.c_uint64),
         ("out_batch_stride", ctypes.c_uint64),
         ("inner", ctypes.c_uint64),
@@ -73,6 +77,7 @@ class PlanOpts(ctypes.Structure):
         ("fourstep_n", ctypes.c_uint64),
         ("fourstep_col0", ctypes.c_uint64),
         ("launch_iters", ctypes.c_uint32),
+        ("input_order", ctypes.c_int),
     ]
 
 
@@ -83,13 +88,20 @@ def _debug_requested():
 class DistGeometry(ctypes.Structure):
     """tfft_dist_geometry (include/tfft.h)."""
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("reserved_", ctypes.c_uint32),
         ("n", ctypes.c_uint64), ("n1", ctypes.c_uint64), ("n2", ctypes.c_uint64), ("cols", ctypes.c_uint64),
         ("rows", ctypes.c_uint64), ("chunk", ctypes.c_uint64), ("world", ctypes.c_int), ("rank", ctypes.c_int),
         ("fused", ctypes.c_int), ("reorder", ctypes.c_int), ("local_passes", ctypes.c_int),
     ]
 
 
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(DistGeometry)       # OUT struct: the library fills at most this many bytes
+
+
 DIST_ID_BYTES = 128
+DIST_SELF_VIA_COMM, DIST_CALLER_BUFFERS = 1, 2          # tfft_dist_plan_create flags
 
 
 def lib_path():
@@ -211,6 +223,14 @@ def load_library():
     L.tfft_copy_d2h.argtypes = [vp, vp, ctypes.c_size_t]
     L.tfft_plan_prepare.restype = ci
     L.tfft_plan_prepare.argtypes = [vp]
+    L.tfft_plan_opts_init.restype = ci
+    L.tfft_plan_opts_init.argtypes = [vp, ctypes.c_size_t]
+    L.tfft_plan_opts_known_size.restype = ci
+    L.tfft_plan_opts_known_size.argtypes = [ctypes.c_size_t]
+    L.tfft_dist_comm_info.restype = ci
+    L.tfft_dist_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    L.tfft_dist_rccl_version.restype = ci
+    L.tfft_dist_rccl_version.argtypes = [ctypes.POINTER(ci)]
     L.tfft_last_error.restype = ctypes.c_char_p
     L.tfft_last_error.argtypes = []
     L.tfft_version.restype = ctypes.c_char_p
@@ -263,15 +283,16 @@ class TfftPlan:
 
     def __init__(self, n, batch=1, device=0, in_batch_stride=0, out_batch_stride=0, preserve_input=False,
                  variant=0, inner=1, scale="sequential", output_order="natural", fourstep_n=0, fourstep_col0=0,
-                 launch_iters=0):
+                 launch_iters=0, input_order="natural"):
         L = load_library()
         self._lib = L
         self._h = ctypes.c_void_p()
         scale = _SCALES[scale] if isinstance(scale, str) else int(scale)
         output_order = _ORDERS[output_order] if isinstance(output_order, str) else int(output_order)
-        opts = PlanOpts(int(in_batch_stride), int(out_batch_stride), int(inner), int(bool(preserve_input)), int(variant),
-                        scale, output_order, int(fourstep_n), int(fourstep_col0), int(launch_iters))
-        self.scale, self.output_order = scale, output_order
+        input_order = _ORDERS[input_order] if isinstance(input_order, str) else int(input_order)
+        opts = PlanOpts(ctypes.sizeof(PlanOpts), 0, int(in_batch_stride), int(out_batch_stride), int(inner), int(bool(preserve_input)),
+                        int(variant), scale, output_order, int(fourstep_n), int(fourstep_col0), int(launch_iters), input_order)
+        self.scale, self.output_order, self.input_order = scale, output_order, input_order
         _check(L.tfft_plan_create(int(n), int(batch), int(device), ctypes.byref(opts), ctypes.byref(self._h)))
         self.n, self.batch, self.device, self.inner = int(n), int(batch), int(device), int(inner)
         self.in_batch_stride = int(in_batch_stride) or 2 * self.n * self.inner
@@ -416,6 +437,13 @@ def dist_geometry(n, world, rank=0):
     return g
 
 
+def dist_rccl_version():
+    """ncclGetVersion of the RCCL bound by the library (e.g. 22703), for run reports."""
+    v = ctypes.c_int(0)
+    _check(load_library().tfft_dist_rccl_version(ctypes.byref(v)))
+    return int(v.value)
+
+
 def dist_unique_id():
     """An ncclUniqueId (bytes) from tfft_dist_unique_id: make it on one rank, carry it to the others."""
     buf = ctypes.create_string_buffer(DIST_ID_BYTES)
@@ -438,6 +466,12 @@ class DistComm:
     def handle(self):
         return self._h
 
+    def info(self):
+        """(ncclCommCount, ncclCommUserRank) of the communicator."""
+        c, r = ctypes.c_int(0), ctypes.c_int(0)
+        _check(self._lib.tfft_dist_comm_info(self._h, ctypes.byref(c), ctypes.byref(r)))
+        return int(c.value), int(r.value)
+
     def close(self):
         h = getattr(self, "_h", None)
         if h:
@@ -456,8 +490,10 @@ class DistPlan:
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         self._comm = comm
+        # caller-owned exchange buffers: the plan then allocates none of its own (TFFT_DIST_CALLER_BUFFERS; 512 MiB at 2^26 on one rank)
+        flags = (DIST_SELF_VIA_COMM if self_via_comm else 0) | (DIST_CALLER_BUFFERS if buffers is not None else 0)
         _check(self._lib.tfft_dist_plan_create(int(n), int(world), int(rank), int(device), comm.handle if comm else None,
-                                               1 if self_via_comm else 0, ctypes.byref(self._h)))
+                                               flags, ctypes.byref(self._h)))
         self.device = int(device)
         g = DistGeometry()
         _check(self._lib.tfft_dist_plan_geometry(self._h, ctypes.byref(g)))

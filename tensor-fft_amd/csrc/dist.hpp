@@ -41,6 +41,7 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
   std::string error;
 };
 
@@ -75,6 +76,7 @@ Rccl* rccl() {
     bind(r.GroupStart, "ncclGroupStart");
     bind(r.GroupEnd, "ncclGroupEnd");
     bind(r.GetErrorString, "ncclGetErrorString");
+    bind(r.GetVersion, "ncclGetVersion");
     if (!ok) {
       dlclose(r.handle);
       r.handle = nullptr;
@@ -124,6 +126,7 @@ int dist_geometry(uint64_t n, int world, int rank, tfft_dist_geometry* g) {
     return fail(TFFT_ERR_ARG, "N = " + std::to_string(n) + " is too small for " + std::to_string(world) +
                                   " ranks: the distributed transform needs N >= 256 * 64 * ranks (64 columns per rank)");
   std::memset(g, 0, sizeof(*g));
+  g->struct_size = static_cast<uint32_t>(sizeof(*g));
   g->n = n;
   g->n1 = n1;
   g->n2 = n / n1;
@@ -159,13 +162,43 @@ struct tfft_dist_plan {
   _Float16 *send_re = nullptr, *send_im = nullptr, *recv_re = nullptr, *recv_im = nullptr;
   _Float16 *tmp_re = nullptr, *tmp_im = nullptr;
   bool self_via_comm = false;   // TFFT_DIST_SELF_VIA_COMM: the own chunk goes through ncclSend / ncclRecv too
+  bool caller_buffers = false;  // TFFT_DIST_CALLER_BUFFERS: no internal exchange block; tfft_dist_plan_set_buffers before the first exec
 };
 
 extern "C" {
 
+namespace {
+// tfft_dist_geometry is an OUT struct: the caller says how many bytes it owns (struct_size), the library fills at most that many.
+constexpr size_t kGeometryMinBytes = offsetof(tfft_dist_geometry, local_passes) + sizeof(int);     // the round-4 layout
+int geometry_out(const tfft_dist_geometry& g, tfft_dist_geometry* out) {
+  if (!out) return fail(TFFT_ERR_ARG, "null geometry pointer");
+  uint32_t sz = 0;
+  std::memcpy(&sz, out, sizeof(sz));
+  if (sz < kGeometryMinBytes || sz > 4096 || (sz % 8))
+    return fail(TFFT_ERR_ARG, "tfft_dist_geometry.struct_size = " + std::to_string(sz) + ": set it to sizeof(tfft_dist_geometry) before the call "
+                                  "(TFFT_DIST_GEOMETRY_INIT); this library writes " + std::to_string(sizeof(g)) + " bytes at most");
+  const size_t copy = std::min<size_t>(sz, sizeof(g));
+  std::memcpy(out, &g, copy);
+  std::memcpy(out, &sz, sizeof(sz));            // the caller's size stays what it was
+  return TFFT_OK;
+}
+}  // namespace
+
 int tfft_dist_geometry_query(uint64_t n, int world, int rank, tfft_dist_geometry* out) {
   g_err.clear();
-  return dist_geometry(n, world, rank, out);
+  tfft_dist_geometry g;
+  const int rc = dist_geometry(n, world, rank, &g);
+  if (rc) return rc;
+  return geometry_out(g, out);
+}
+
+int tfft_dist_rccl_version(int* version) {
+  g_err.clear();
+  if (!version) return fail(TFFT_ERR_ARG, "null argument");
+  int rc = rccl_ready();
+  if (rc) return rc;
+  TFFT_NCCL(rccl()->GetVersion(version));
+  return TFFT_OK;
 }
 
 int tfft_dist_unique_id(void* id128) {
@@ -219,6 +252,16 @@ int tfft_dist_comm_destroy(void* comm) {
   return TFFT_OK;
 }
 
+int tfft_dist_comm_info(void* comm, int* count, int* rank) {
+  g_err.clear();
+  if (!comm) return fail(TFFT_ERR_ARG, "null communicator");
+  int rc = rccl_ready();
+  if (rc) return rc;
+  if (count) TFFT_NCCL(rccl()->CommCount(static_cast<ncclComm_t>(comm), count));
+  if (rank) TFFT_NCCL(rccl()->CommUserRank(static_cast<ncclComm_t>(comm), rank));
+  return TFFT_OK;
+}
+
 int tfft_dist_group_start(void) {
   g_err.clear();
   int rc = rccl_ready();
@@ -253,7 +296,7 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
   g_err.clear();
   if (!out) return fail(TFFT_ERR_ARG, "null plan pointer");
   *out = nullptr;
-  if (flags & ~TFFT_DIST_SELF_VIA_COMM) return fail(TFFT_ERR_ARG, "unknown flag");
+  if (flags & ~(TFFT_DIST_SELF_VIA_COMM | TFFT_DIST_CALLER_BUFFERS)) return fail(TFFT_ERR_ARG, "unknown flag");
   if ((flags & TFFT_DIST_SELF_VIA_COMM) && !comm) return fail(TFFT_ERR_ARG, "TFFT_DIST_SELF_VIA_COMM needs a communicator");
   tfft_dist_geometry g;
   int rc = dist_geometry(n, world, rank, &g);
@@ -273,6 +316,7 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
   p->device = device_id;
   p->comm = static_cast<ncclComm_t>(comm);
   p->self_via_comm = (flags & TFFT_DIST_SELF_VIA_COMM) != 0;
+  p->caller_buffers = (flags & TFFT_DIST_CALLER_BUFFERS) != 0;
   const bool two_sided = world > 1 || p->self_via_comm;      // separate receive buffers
   auto bail = [&](int code) {
     const std::string keep = g_err;
@@ -281,7 +325,7 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
     return code;
   };
   // column pass: n = N1 along the strided axis, C columns, four-step twiddle with this rank's column offset
-  tfft_plan_opts co{};
+  tfft_plan_opts co = TFFT_PLAN_OPTS_INIT;
   co.inner = g.cols;
   co.in_batch_stride = g.n1 * g.cols;
   co.out_batch_stride = g.n1 * g.cols;
@@ -291,7 +335,7 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
   rc = create_plan(g.n1, 1, device_id, &co, InternalOpts{}, &p->col);
   if (rc) return bail(rc);
   // row transforms: K contiguous rows of N2, read from the receive buffer in place (segments) or behind a re-order pass
-  tfft_plan_opts ro{};
+  tfft_plan_opts ro = TFFT_PLAN_OPTS_INIT;
   ro.in_batch_stride = g.reorder || world == 1 ? g.n2 : g.cols;
   ro.out_batch_stride = g.n2;
   ro.preserve_input = 1;
@@ -304,24 +348,32 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
   if (rc) return bail(rc);
   const size_t plane = static_cast<size_t>(g.n / static_cast<uint64_t>(world)) * sizeof(_Float16);   // N / P halves
   const size_t row_ws = tfft_plan_workspace_bytes(p->row);
-  const size_t total = plane * (two_sided ? 4 : 2) + (g.reorder ? 2 * plane : 0) + row_ws;
-  int prev = 0;
-  hipError_t e = hipGetDevice(&prev);
-  if (e == hipSuccess) e = hipSetDevice(device_id);
-  if (e == hipSuccess) e = hipMalloc(&p->block, total);
-  (void)hipSetDevice(prev);
-  if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(distributed plan buffers)"));
-  uint8_t* b = static_cast<uint8_t*>(p->block);
-  p->send_re = reinterpret_cast<_Float16*>(b);
-  p->send_im = reinterpret_cast<_Float16*>(b + plane);
-  b += 2 * plane;
-  if (two_sided) {
-    p->recv_re = reinterpret_cast<_Float16*>(b);
-    p->recv_im = reinterpret_cast<_Float16*>(b + plane);
+  // (TFFT_DIST_CALLER_BUFFERS: the exchange buffers come from the caller, e.g. tensors of a framework whose own collective
+  // sends them; the plan then only owns the re-order and row-plan scratch)
+  const size_t exch = p->caller_buffers ? 0 : plane * (two_sided ? 4 : 2);
+  const size_t total = exch + (g.reorder ? 2 * plane : 0) + row_ws;
+  uint8_t* b = nullptr;
+  if (total) {
+    int prev = 0;
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess) e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipMalloc(&p->block, total);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(distributed plan buffers)"));
+    b = static_cast<uint8_t*>(p->block);
+  }
+  if (!p->caller_buffers) {
+    p->send_re = reinterpret_cast<_Float16*>(b);
+    p->send_im = reinterpret_cast<_Float16*>(b + plane);
     b += 2 * plane;
-  } else {
-    p->recv_re = p->send_re;       // one rank: nothing to exchange, the row pass reads what the column pass wrote
-    p->recv_im = p->send_im;
+    if (two_sided) {
+      p->recv_re = reinterpret_cast<_Float16*>(b);
+      p->recv_im = reinterpret_cast<_Float16*>(b + plane);
+      b += 2 * plane;
+    } else {
+      p->recv_re = p->send_re;       // one rank: nothing to exchange, the row pass reads what the column pass wrote
+      p->recv_im = p->send_im;
+    }
   }
   if (g.reorder) {
     p->tmp_re = reinterpret_cast<_Float16*>(b);
@@ -339,8 +391,7 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
 int tfft_dist_plan_geometry(const tfft_dist_plan* p, tfft_dist_geometry* out) {
   g_err.clear();
   if (!p || !out) return fail(TFFT_ERR_ARG, "null argument");
-  *out = p->g;
-  return TFFT_OK;
+  return geometry_out(p->g, out);
 }
 
 int tfft_dist_plan_buffers(const tfft_dist_plan* p, void** send_re, void** send_im, void** recv_re, void** recv_im) {
@@ -360,14 +411,24 @@ int tfft_dist_plan_set_buffers(tfft_dist_plan* p, void* send_re, void* send_im, 
   if ((reinterpret_cast<uintptr_t>(send_re) | reinterpret_cast<uintptr_t>(send_im) | reinterpret_cast<uintptr_t>(recv_re) |
        reinterpret_cast<uintptr_t>(recv_im)) & 15)
     return fail(TFFT_ERR_ARG, "buffers must be 16-byte aligned");
+  // validate first, commit on success: each buffer is the range [ptr, ptr + N / world halves); the two send planes must not
+  // overlap each other, and with a real exchange no receive range may overlap a send range or the other receive range (ncclRecv
+  // would write into bytes that are still being sent)
+  const bool two_sided = p->g.world > 1 || p->self_via_comm;
+  const size_t bytes = static_cast<size_t>(p->g.n / static_cast<uint64_t>(p->g.world)) * sizeof(_Float16);
+  auto overlap = [bytes](const void* a, const void* b2) {
+    const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b2);
+    return x < y + bytes && y < x + bytes;
+  };
+  if (overlap(send_re, send_im)) return fail(TFFT_ERR_ARG, "the two send planes overlap");
+  if (two_sided && (overlap(recv_re, recv_im) || overlap(recv_re, send_re) || overlap(recv_re, send_im) || overlap(recv_im, send_re) ||
+                    overlap(recv_im, send_im)))
+    return fail(TFFT_ERR_ARG, "send and receive buffers must be distinct, non-overlapping ranges of N / world halves each");
   p->send_re = static_cast<_Float16*>(send_re);
   p->send_im = static_cast<_Float16*>(send_im);
   // one rank and no collective: nothing moves between the phases, the row transforms read what the column pass wrote
-  const bool two_sided = p->g.world > 1 || p->self_via_comm;
   p->recv_re = two_sided ? static_cast<_Float16*>(recv_re) : p->send_re;
   p->recv_im = two_sided ? static_cast<_Float16*>(recv_im) : p->send_im;
-  if (two_sided && (recv_re == send_re || recv_im == send_im || recv_re == send_im || recv_im == send_re))
-    return fail(TFFT_ERR_ARG, "send and receive buffers must be distinct");
   return TFFT_OK;
 }
 
@@ -377,6 +438,8 @@ int dist_check(const tfft_dist_plan* p) {
   int cur = 0;
   TFFT_HIP(hipGetDevice(&cur));
   if (cur != p->device) return fail(TFFT_ERR_ARG, "plan was created for another device than the current one");
+  if (!p->send_re || !p->recv_re)
+    return fail(TFFT_ERR_ARG, "this plan was created with TFFT_DIST_CALLER_BUFFERS: call tfft_dist_plan_set_buffers before the first execution");
   return TFFT_OK;
 }
 }  // namespace

@@ -17,6 +17,7 @@ constexpr int kSlots = 4;
 constexpr size_t kSmall = size_t{1} << 20;      // below this a plain hipMemcpy is as good
 
 struct Ring {
+  std::mutex busy;      // one transfer at a time PER DEVICE: host threads that feed different devices do not serialise
   int device = -1;
   void* slot[kSlots] = {};
   hipEvent_t done[kSlots] = {};
@@ -24,13 +25,13 @@ struct Ring {
   bool ok = false;
 };
 
-// one ring per device, created on first use, kept for the life of the process (64 MiB of pinned memory per device used)
-inline std::mutex& ring_mutex() {
-  static std::mutex m;
-  return m;
-}
+// One ring per device, created on first use, kept for the life of the process (64 MiB of pinned memory per device used). The
+// map is guarded by a short global lock (std::map nodes do not move, so the returned pointer stays valid); a transfer then
+// holds only ITS device's Ring::busy. Call with the ring's `busy` NOT held; creation happens under the global lock.
 inline Ring* ring_for(int device, std::string* err) {
+  static std::mutex map_mutex;
   static std::map<int, Ring> rings;
+  std::lock_guard<std::mutex> lock(map_mutex);
   Ring& r = rings[device];
   if (r.ok) return &r;
   r.device = device;
@@ -69,8 +70,9 @@ inline void host_copy(void* dst, const void* src, size_t bytes) {
 
 extern "C" {
 
-// Blocking (like the reference's cudaMemcpy): returns when the bytes are on the device. `stream`: work already queued on it
-// that READS or WRITES dst must have been ordered by the caller (this call synchronises with its own private stream only).
+// Blocking (like the reference's cudaMemcpy, src/base/DataHandler.h:45-53): returns when the bytes are on the device, and, like
+// a blocking hipMemcpy on the null stream, it first waits for the work already queued on the device: a kernel that still reads
+// or writes dst (ComputeFFT is asynchronous; a following CopyDataHostToDevice must not overwrite its input under it).
 int tfft_copy_h2d(void* dst_device, const void* src_host, size_t bytes) {
   g_err.clear();
   if (!dst_device || !src_host) return fail(TFFT_ERR_ARG, "null pointer");
@@ -81,10 +83,11 @@ int tfft_copy_h2d(void* dst_device, const void* src_host, size_t bytes) {
   }
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(staging::ring_mutex());
+  TFFT_HIP(hipDeviceSynchronize());      // order against everything queued on this device (see above)
   std::string err;
   staging::Ring* r = staging::ring_for(dev, &err);
   if (!r) return fail(TFFT_ERR_HIP, err);
+  std::lock_guard<std::mutex> lock(r->busy);
   size_t off = 0;
   for (int i = 0; off < bytes; ++i) {
     const int s = i % staging::kSlots;
@@ -110,10 +113,10 @@ int tfft_copy_d2h(void* dst_host, const void* src_device, size_t bytes) {
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
   TFFT_HIP(hipDeviceSynchronize());      // (as a blocking hipMemcpy would: everything that produces src has finished)
-  std::lock_guard<std::mutex> lock(staging::ring_mutex());
   std::string err;
   staging::Ring* r = staging::ring_for(dev, &err);
   if (!r) return fail(TFFT_ERR_HIP, err);
+  std::lock_guard<std::mutex> lock(r->busy);
   const size_t chunks = (bytes + staging::kChunk - 1) / staging::kChunk;
   auto issue = [&](size_t c) -> hipError_t {
     const int s = static_cast<int>(c % staging::kSlots);

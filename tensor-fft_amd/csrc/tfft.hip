@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -401,7 +402,11 @@ int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, vo
   TFFT_LAUNCH(k4096r::fft4096r_kernel<R>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
+                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables)
+#ifdef TFFT_DEBUG_KERNELS
+                     , static_cast<unsigned long long*>(nullptr)
+#endif
+                     );
   return TFFT_OK;
 }
 
@@ -418,10 +423,19 @@ int launch_k4096r(const tfft_plan* p, int radix, const void* in_re, const void* 
 int launch_rows2d(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                   uint64_t image_stride, uint32_t iterations, hipStream_t s) {
   const uint32_t grid = std::min<uint32_t>(iterations, static_cast<uint32_t>(p->num_cus));
+#ifdef TFFT_DEBUG_KERNELS
+  unsigned long long* stamps = nullptr;      // measurement hook of tools/exp_rows_phases.py
+  if (debug_variants_enabled())
+    if (const char* e = std::getenv("TFFT_ROWS_STAMPS_PTR")) stamps = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0));
+#endif
   TFFT_LAUNCH((k4096r::fft4096r_kernel<8, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), k4096::Addr{image_stride, image_stride, 0, 0},
-                     k4096::Addr{image_stride, image_stride, 0, 0}, iterations, static_cast<const uint8_t*>(p->d_tables));
+                     k4096::Addr{image_stride, image_stride, 0, 0}, iterations, static_cast<const uint8_t*>(p->d_tables)
+#ifdef TFFT_DEBUG_KERNELS
+                     , stamps
+#endif
+                     );
   if (!g_prepare) TFFT_HIP(hipGetLastError());
   return TFFT_OK;
 }
@@ -971,7 +985,7 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   const uint64_t n = p->n, n2 = tfft_plan_transposed_n2(n), n1 = n / n2;
   if (p->batch * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "batch * N1 too large for one launch");
   const int mode = p->scale_mode;
-  tfft_plan_opts co{};
+  tfft_plan_opts co = TFFT_PLAN_OPTS_INIT;
   co.in_batch_stride = p->in_stride;
   co.out_batch_stride = n;
   co.inner = n2;
@@ -988,7 +1002,7 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   co.launch_iters = p->launch_iters;
   int rc = create_plan(n1, p->batch, device_id, &co, InternalOpts{}, &p->sub_col);
   if (rc) return rc;
-  tfft_plan_opts ro{};
+  tfft_plan_opts ro = TFFT_PLAN_OPTS_INIT;
   ro.in_batch_stride = n2;
   ro.out_batch_stride = n2;
   ro.preserve_input = 1;
@@ -1003,10 +1017,41 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   return create_plan(n2, p->batch * n1, device_id, &ro, ri, &p->sub_row);
 }
 
-int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts, const InternalOpts& io, tfft_plan** out) {
+// tfft_plan_opts as the caller holds it -> the library's own (current) layout: exactly struct_size bytes are read, every
+// field beyond them is 0. Sizes: include/tfft.h (struct_size).
+constexpr size_t kOptsSizes[] = {48, 64, 72};
+static_assert(sizeof(tfft_plan_opts) == 72 && offsetof(tfft_plan_opts, fourstep_n) == 48 && offsetof(tfft_plan_opts, launch_iters) == 64,
+              "tfft_plan_opts layout changed: add the new size to kOptsSizes and to include/tfft.h");
+inline bool opts_size_known(size_t bytes) {
+  for (size_t k : kOptsSizes)
+    if (k == bytes) return true;
+  return false;
+}
+int normalise_opts(const tfft_plan_opts* opts, tfft_plan_opts* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->struct_size = static_cast<uint32_t>(sizeof(*o));
+  if (!opts) return TFFT_OK;
+  uint32_t sz = 0;
+  std::memcpy(&sz, opts, sizeof(sz));           // (only the first four bytes are known to exist)
+  if (!opts_size_known(sz))
+    return fail(TFFT_ERR_ARG, "tfft_plan_opts.struct_size = " + std::to_string(sz) + " is not the size of a layout this library knows (48, 64, " +
+                                  std::to_string(sizeof(*o)) + "): initialise the options with TFFT_PLAN_OPTS_INIT or tfft_plan_opts_init()");
+  std::memcpy(o, opts, sz);
+  o->struct_size = static_cast<uint32_t>(sizeof(*o));
+  if (o->reserved_) return fail(TFFT_ERR_ARG, "tfft_plan_opts.reserved_ must be 0");
+  return TFFT_OK;
+}
+
+int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* caller_opts, const InternalOpts& io, tfft_plan** out) {
   g_err.clear();
   if (!out) return fail(TFFT_ERR_ARG, "null plan pointer");
   *out = nullptr;
+  tfft_plan_opts norm;
+  {
+    const int rc0 = normalise_opts(caller_opts, &norm);
+    if (rc0) return rc0;
+  }
+  const tfft_plan_opts* const opts = &norm;
   if (!is_pow2(n)) return fail(TFFT_ERR_NOT_POW2, "Error! Input size has to be a power of 2!");
   if (n < 2) return fail(TFFT_ERR_TOO_SMALL, "Error! Input size has to be at least 2");
   if (batch == 0 || batch > 0xffffffffull) return fail(TFFT_ERR_ARG, "batch must be in [1, 2^32)");
@@ -1155,6 +1200,18 @@ extern "C" {
 
 int tfft_plan_create(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts, tfft_plan** out) {
   return create_plan(n, batch, device_id, opts, InternalOpts{}, out);
+}
+
+int tfft_plan_opts_known_size(size_t bytes) { return opts_size_known(bytes) ? 1 : 0; }
+
+int tfft_plan_opts_init(tfft_plan_opts* opts, size_t bytes) {
+  g_err.clear();
+  if (!opts) return fail(TFFT_ERR_ARG, "null options pointer");
+  if (!opts_size_known(bytes)) return fail(TFFT_ERR_ARG, "tfft_plan_opts_init: " + std::to_string(bytes) + " bytes is not the size of a layout this library knows");
+  std::memset(opts, 0, bytes);
+  const uint32_t sz = static_cast<uint32_t>(bytes);
+  std::memcpy(opts, &sz, sizeof(sz));
+  return TFFT_OK;
 }
 
 uint64_t tfft_plan_transposed_n2(uint64_t n) {
@@ -1323,7 +1380,7 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
     rc = create_plan(4096, 1, device_id, nullptr, rio, &p->row);
     if (rc == TFFT_OK) {
       // pass 2: one radix-512 column pass per block of 512 intermediate rows; block s of an image writes rows 8 k' + s
-      tfft_plan_opts co{};
+      tfft_plan_opts co = TFFT_PLAN_OPTS_INIT;
       co.in_batch_stride = 512 * cols;
       co.out_batch_stride = rows * cols;
       co.inner = cols;
@@ -1344,13 +1401,13 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
       }
     }
   } else {
-    tfft_plan_opts ro{};
+    tfft_plan_opts ro = TFFT_PLAN_OPTS_INIT;
     ro.in_batch_stride = cols;        // fully planar lines
     ro.out_batch_stride = cols;
     ro.preserve_input = 1;
     rc = tfft_plan_create(cols, batch * rows, device_id, &ro, &p->row);
     if (rc == TFFT_OK) {
-      tfft_plan_opts co{};
+      tfft_plan_opts co = TFFT_PLAN_OPTS_INIT;
       co.in_batch_stride = rows * cols;
       co.out_batch_stride = rows * cols;
       co.inner = cols;

@@ -130,6 +130,12 @@ class HipEngine:
         return plan, send_re, send_im, recv_re, recv_im, mk(), mk()
 
 
+class DistSetupError(RuntimeError):
+    """Creating the native communicator or the distributed plan failed on at least one rank. Raised on EVERY rank of the
+    group together (the ranks agree on the outcome before anyone leaves the constructor), so callers can fall back to another
+    transport in lock-step instead of leaving peers blocked in a collective."""
+
+
 class DistributedFFT1D:
     def __init__(self, n, group=None, engine=None, input_layout="columns", output_layout="transposed", fused=None,
                  transport=None, self_via_comm=False):
@@ -189,19 +195,70 @@ class DistributedFFT1D:
                     raise ValueError("transport must be 'rccl' or 'torch'")
                 self.transport = transport
                 self._via = bool(self_via_comm) and transport == "rccl"
-                self._comm = self._native_comm(engine) if (transport == "rccl" and (p > 1 or self._via)) else None
-                self._core = engine.dist_plan(n, p, self.rank, comm=self._comm, self_via_comm=self._via)
-                self.geometry = self._core[0].geometry
+                self._comm = None
+                # Everything below can fail on one rank only (dlopen of librccl, ncclCommInitRank, a hipMalloc); a rank that left
+                # the constructor alone would strand its peers in the next collective. So: every step ends with an agreement over
+                # the process group, and all ranks raise DistSetupError together.
+                why = None
+                try:
+                    if transport == "rccl" and (p > 1 or self._via):
+                        self._comm = self._native_comm(engine)
+                except Exception as e:      # noqa: BLE001
+                    why = f"{type(e).__name__}: {e}"
+                why = self._agree(why, "creating the RCCL communicator")
+                if why is None:
+                    try:
+                        self._core = engine.dist_plan(n, p, self.rank, comm=self._comm, self_via_comm=self._via)
+                        self.geometry = self._core[0].geometry
+                    except Exception as e:      # noqa: BLE001
+                        why = f"{type(e).__name__}: {e}"
+                    why = self._agree(why, "creating the distributed plan")
+                if why is not None:
+                    self.close()
+                    raise DistSetupError(why)
+
+    def _agree(self, why, what):
+        """All ranks learn whether `what` worked everywhere: returns None if it did, else a message (the local failure, or
+        that another rank failed). One small all-reduce on the process group's own device type."""
+        dist = self.dist
+        if self.world == 1 or not dist.is_initialized():
+            return why
+        import torch
+
+        dev = f"cuda:{self.engine.device}" if dist.get_backend(self.group) == "nccl" else "cpu"
+        ok = torch.tensor([0.0 if why else 1.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if float(ok[0]) == 1.0:
+            return None
+        return why or f"{what} failed on another rank"
+
+    def close(self):
+        """Destroys the distributed plan and the communicator this object created (idempotent)."""
+        core, self._core = getattr(self, "_core", None), None
+        if core is not None:
+            core[0].close()
+        comm, self._comm = getattr(self, "_comm", None), None
+        if comm is not None:
+            comm.close()
 
     def _native_comm(self, engine):
         """An RCCL communicator of this process group's ranks, created through the C ABI: rank 0 makes the id
         (tfft_dist_unique_id = ncclGetUniqueId), the torch process group carries it, every rank joins
         (tfft_dist_comm_create = ncclCommInitRank)."""
         dist = self.dist
-        box = [engine.capi.dist_unique_id() if self.rank == 0 else None]
+        box = [None]
+        if self.rank == 0:
+            # rank 0 may fail right here (librccl not loadable, a missing symbol): the peers are about to enter the broadcast,
+            # so what travels is either the id or the error, and everybody raises or continues together
+            try:
+                box = [engine.capi.dist_unique_id()]
+            except Exception as e:      # noqa: BLE001
+                box = [("error", f"{type(e).__name__}: {e}")]
         if self.world > 1:
             src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
             dist.broadcast_object_list(box, src=src, group=self.group)
+        if isinstance(box[0], tuple):
+            raise RuntimeError("rank 0 could not create the RCCL unique id: " + box[0][1])
         return engine.capi.DistComm(self.world, self.rank, box[0], engine.device)
 
     # ---- layouts (what each rank holds, as index arrays into x / X; used by callers and tests)
@@ -304,6 +361,32 @@ class DistributedFFT1D:
         elif self.output_layout == "natural":
             re, im = self._transpose_last(re, im, self.n1, self.c)
         return re, im
+
+    def phase_times(self, re, im, reps=10):
+        """Mean milliseconds of the three phases of the fused GPU path (column pass / exchange / row transforms), from HIP
+        events on the one stream all three are enqueued on: where a distributed transform spends its time. Plain layouts only.
+        Returns {"pre_ms", "exchange_ms", "post_ms"}; the output buffers hold a valid transform afterwards."""
+        import torch
+
+        if self._core is None or self.input_layout != "columns" or self.output_layout != "transposed":
+            raise ValueError("phase_times: needs the fused GPU path with the plain layouts")
+        plan, send_re, send_im, recv_re, recv_im, out_re, out_im = self._core
+        native = self.transport == "rccl" and (self.world > 1 or self._via)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+        for r in range(reps):
+            ev[r][0].record()
+            plan.pre(re, im)
+            ev[r][1].record()
+            if native:
+                plan.exchange()
+            else:
+                self._exchange(send_re, send_im, "main", out=(recv_re, recv_im))
+            ev[r][2].record()
+            plan.post(out_re, out_im)
+            ev[r][3].record()
+        torch.cuda.synchronize()
+        mean = lambda i: sum(e[i].elapsed_time(e[i + 1]) for e in ev) / reps      # noqa: E731
+        return {"pre_ms": mean(0), "exchange_ms": mean(1), "post_ms": mean(2)}
 
     def _transpose_last(self, re, im, rows, cols):
         """[rows][cols] -> [cols][rows] (k1 becomes the fast index); pure data movement into buffers kept by this object."""

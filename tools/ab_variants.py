@@ -67,6 +67,17 @@ if args.shape.startswith("2d:"):
     for spec, p in plans2:
         ms = statistics.median(res[spec])
         print(f"2D 4096x4096 x {images} {spec:>12s}: {ms:.3f} ms (min {min(res[spec]):.3f}, max {max(res[spec]):.3f})  {half/ms/1e6:7.1f} Gsamples/s", flush=True)
+    # builds that only differ in scheduling must agree bit for bit
+    ref = None
+    for spec, p in plans2:
+        y.fill_(float("nan"))
+        p.exec(x[:half], x[half:], y[:half], y[half:])
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = y.clone()
+        else:
+            same = bool((ref.view(torch.int16) == y.view(torch.int16)).all())
+            print(f"   {spec}: output {'bit-identical to' if same else 'DIFFERS from'} {plans2[0][0]}", flush=True)
     sys.exit(0)
 f = [int(v) for v in args.shape.split(":")]
 n, b, inner = f[0], f[1], (f[2] if len(f) > 2 else 1)
