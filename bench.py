@@ -25,7 +25,14 @@ At 1 GPU `other_configs` carries short measurements of the other BASELINE config
 order, 2D 4096^2 x 64, single 2^26) and neighbouring lengths, taken AFTER the timed region, each with an oracle check of
 a sampled transform / image; they do not enter `value`. With N > 1 GPUs `other_configs` carries BASELINE configs[4b] instead:
 ONE transform of N = 2^26 spread over the N GPUs with a single RCCL exchange (tfft_dist_exec), checked by Parseval over all ranks
-and four bins per rank against a direct fp64 DFT sum.
+and four bins per rank against a direct fp64 DFT sum; the entry reports the three phases of the transform separately (column pass,
+exchange, row passes: HIP events on the one stream), the communicator's size, the RCCL version and whether the fallback transport
+was taken, and under N > 1 the line carries every rank's kernel time.
+
+Failure policy: a failed self-check of the HEADLINE ends the run without a line (a broken kernel cannot post a number). Every
+`other_configs` entry, configs[4b] included, is isolated: a failed check or an exception becomes {"error": ...} under the entry's
+name, the line is still printed, and the process exits with code 1 (3 when the configs[4b] entry had to be abandoned after
+--dist-timeout seconds).
 """
 import argparse
 import json
@@ -341,31 +348,36 @@ def self_launch(n_ranks, script, script_args, nproc_visible=None):
 def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm=False):
     """BASELINE configs[4b]: ONE transform of N = 2^26 spread over the `world` GPUs, four-step with a single RCCL exchange
     (tfft_dist_exec: column pass -> ncclSend / ncclRecv group -> row transforms, all on one stream). Every rank calls this;
-    returns the report (identical on all ranks). Checked: Parseval over all ranks and four spectrum bins per rank against a
-    direct fp64 DFT sum of the (regenerated) input."""
+    returns the report (identical on all ranks). Reported: whole-transform time, the three phases separately (HIP events on the one
+    stream around tfft_dist_exec_pre / _exchange / _post, min and max over ranks), the facts of the communicator, and the checks:
+    Parseval over all ranks and four spectrum bins per rank against a direct fp64 DFT sum of the (regenerated) input."""
     import numpy as np
-    from tensor_fft_amd.distributed import DistributedFFT1D, HipEngine
+    from tensor_fft_amd import capi
+    from tensor_fft_amd.distributed import DistributedFFT1D, DistSetupError, HipEngine
 
     n = 1 << 26
-    # The exchange runs inside the C ABI over its own RCCL communicator. If creating that fails on ANY rank (it is the one piece
-    # no single-GPU box can rehearse with more than one rank), ALL ranks agree to fall back to the same plan with the exchange
-    # over the torch process group, and the report says so.
-    f, why = None, ""
+    # The exchange runs inside the C ABI over its own RCCL communicator. DistributedFFT1D makes the ranks AGREE on whether creating
+    # it worked (it is the one piece no single-GPU box can rehearse with more than one rank): on failure every rank gets
+    # DistSetupError together, and all fall back, in lock-step, to the same plan with the exchange over the torch process group.
+    want_native = world > 1 or self_via_comm
+    why = None
     try:
-        f = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="rccl" if (world > 1 or self_via_comm) else None,
-                             self_via_comm=self_via_comm)
-    except Exception as e:      # noqa: BLE001
-        why = f"{type(e).__name__}: {e}"
-    if world > 1:
-        ok = torch.tensor([1.0 if f is not None else 0.0], device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok[0]) == 0.0:
-            f = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="torch")
-            why = why or "another rank could not create its communicator"
-    elif f is None:
-        raise RuntimeError(why)
+        f = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="rccl" if want_native else None, self_via_comm=self_via_comm)
+    except DistSetupError as e:
+        if world == 1:
+            raise
+        why = str(e)
+        f = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="torch")
     g = f.geometry
     n1, n2, c, k = int(g.n1), int(g.n2), int(g.cols), int(g.rows)
+    comm_info = None
+    if f._comm is not None:
+        cnt, me = f._comm.info()
+        comm_info = {"ncclCommCount": cnt, "ncclCommUserRank_of_rank0": me}
+    try:
+        rccl_version = capi.dist_rccl_version() if want_native else None
+    except capi.TfftError as e:
+        rccl_version = f"unavailable: {e}"
     # the whole signal on every rank (2 x 128 MiB; a pure function of the seed), this rank's columns sliced out of it
     x = torch.empty(2 * n, dtype=torch.float16, device="cuda")
     tf.synth_uniform(x, x[n:], n, 1, seed=SEED + 26)
@@ -387,24 +399,32 @@ def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm
         re, im = f.forward(in_re, in_im)
     fence()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    # local work only (column pass + row transforms, no exchange) for the split of the time
-    plan = f._core[0]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    o_re, o_im = f._core[5], f._core[6]
+    # the three phases, each between two HIP events on the stream all of them are enqueued on
     fence()
-    e0.record()
-    for _ in range(reps):
-        plan.pre(in_re, in_im)
-        plan.post(o_re, o_im)
-    e1.record()
+    ph = f.phase_times(in_re, in_im, reps)
+    fence()
+    re, im = f.forward(in_re, in_im)
     torch.cuda.synchronize()
-    local_ms = e0.elapsed_time(e1) / reps
-    re, im = f.forward(in_re, in_im)          # (the local-only runs above left stale receive buffers behind)
-    torch.cuda.synchronize()
-    t = torch.tensor([ms, local_ms], dtype=torch.float64, device="cuda")
+    keys = ("pre_ms", "exchange_ms", "post_ms")
+    t_max = torch.tensor([ms] + [ph[q] for q in keys], dtype=torch.float64, device="cuda")
+    t_min = t_max.clone()
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ms, local_ms = float(t[0]), float(t[1])
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_min, op=dist.ReduceOp.MIN)
+    ms = float(t_max[0])
+    phases = {q: {"max_over_ranks": float(t_max[1 + i]), "min_over_ranks": float(t_min[1 + i])} for i, q in enumerate(keys)}
+    local_ms = phases["pre_ms"]["max_over_ranks"] + phases["post_ms"]["max_over_ranks"]
+    sent = 2 * (world - 1) * int(g.chunk) * 2                       # bytes this rank sends (= receives): both planes
+    if self_via_comm:
+        sent += 2 * int(g.chunk) * 2                                # (rehearsal: the own chunk travels through RCCL too)
+    report = {
+        "ms": ms, "gsamples_per_s": n / ms / 1e6, "phases": phases, "local_ms_without_exchange": local_ms,
+        "n1": n1, "n2": n2, "columns_per_rank": c, "rows_per_rank": k, "local_passes": int(g.local_passes),
+        "reorder_pass": bool(g.reorder), "transport": f.transport, "transport_fallback_taken": why is not None,
+        "transport_fallback_reason": why, "communicator": comm_info, "rccl_version": rccl_version,
+        "bytes_through_the_collective_per_rank": sent,
+        "exchange_GBps_per_rank": (sent / (phases["exchange_ms"]["max_over_ranks"] * 1e-3) / 1e9) if sent else None,
+    }
     # ---- checks
     xs = x.double()
     e_in = float((xs * xs).sum()) / n
@@ -413,14 +433,15 @@ def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm
         dist.all_reduce(e_out)
     e_out = float(e_out)
     if not abs(e_out - e_in) / e_in < 5e-3:
-        return {"error": f"self-check failed: distributed N=2^26 Parseval {e_out} vs {e_in}"}
+        report["error"] = f"self-check failed: distributed N=2^26 Parseval {e_out} vs {e_in}"
+        return report
     tt = torch.arange(n, device="cuda", dtype=torch.float64)
     worst = 0.0
     for kk, k2 in ((0, 1), (k // 2, n2 // 3), (k - 1, n2 - 5), (1 % k, 4097)):
         k1 = rank * k + kk
         bin_ = k1 + n1 * k2                                         # X[k1 + N1 k2] lives at [kk][k2] of this rank
-        ph = -2.0 * np.pi * ((tt * bin_) % n) / n
-        cs, sn = torch.cos(ph), torch.sin(ph)
+        phz = -2.0 * np.pi * ((tt * bin_) % n) / n
+        cs, sn = torch.cos(phz), torch.sin(phz)
         er = float((xs[:n] * cs - xs[n:] * sn).sum()) / n
         ei = float((xs[:n] * sn + xs[n:] * cs).sum()) / n
         worst = max(worst, abs(float(re[kk * n2 + k2]) - er), abs(float(im[kk * n2 + k2]) - ei))
@@ -430,17 +451,12 @@ def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm
     worst = float(w[0])
     rms = (e_in / n / 2) ** 0.5
     if not worst < 8 * 2.0 ** -11 * max(rms, 2.0 ** -14):
-        return {"error": f"self-check failed: distributed N=2^26 bins off by {worst:.3e} (spectrum rms {rms:.3e})"}
-    sent = 2 * (world - 1) * int(g.chunk) * 2                       # bytes this rank sends (= receives): both planes
-    exch_ms = max(ms - local_ms, 1e-6)
-    return {
-        "ms": ms, "gsamples_per_s": n / ms / 1e6, "local_ms_without_exchange": local_ms,
-        "n1": n1, "n2": n2, "columns_per_rank": c, "rows_per_rank": k, "local_passes": int(g.local_passes),
-        "reorder_pass": bool(g.reorder), "transport": f.transport, "transport_fallback_reason": why or None,
-        "bytes_sent_per_rank": sent, "exchange_GBps_per_rank": (sent / (exch_ms * 1e-3) / 1e9) if world > 1 else None,
-        "check": f"Parseval over all ranks + 4 bins per rank against a direct fp64 DFT sum on the device: max |delta| {worst:.2e} "
-                 f"(spectrum rms {rms:.2e})",
-    }
+        report["error"] = f"self-check failed: distributed N=2^26 bins off by {worst:.3e} (spectrum rms {rms:.3e})"
+        return report
+    report["check"] = (f"Parseval over all ranks + 4 bins per rank against a direct fp64 DFT sum on the device: max |delta| {worst:.2e} "
+                       f"(spectrum rms {rms:.2e})")
+    f.close()
+    return report
 
 
 def main():
@@ -456,6 +472,10 @@ def main():
     ap.add_argument("--dist-self-via-comm", action="store_true",
                     help="rehearsal aid for a one-GPU box (with --with-dist): the configs[4b] entry creates its RCCL communicator and "
                          "routes the own chunk through ncclSend / ncclRecv, next to the torch process group's own communicator")
+    ap.add_argument("--only-dist-entry", action="store_true",
+                    help="of the other_configs entries run only configs[4b] (with --with-dist on one rank: the rehearsal the GPU tests use)")
+    ap.add_argument("--dist-timeout", type=float, default=300.0,
+                    help="seconds the configs[4b] entry may take before the line is printed without it and the run exits with code 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short extra measurements of the other BASELINE configs (reported under 'other_configs')")
@@ -539,7 +559,13 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps            # launches are back to back on one stream
+    kernel_ms_per_rank = [kernel_ms]
     if dist is not None:
+        # every rank's own kernel time, so that one slow GPU is visible in the weak-scaling line (the line's kernel_ms is the max)
+        mine = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        kernel_ms_per_rank = [float(v[0]) for v in every]
         t = torch.tensor([wall, kernel_ms, cold_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kernel_ms, cold_ms = float(t[0]), float(t[1]), float(t[2])
@@ -569,7 +595,10 @@ def main():
         from oracle import orc
 
         ids = sorted({0, 1, batch // 2 + 3, batch - 1})
-        oracle_err = check_transforms(torch, orc, y, N, batch, ids, first_fft=first_fft)
+        try:
+            oracle_err = check_transforms(torch, orc, y, N, batch, ids, first_fft=first_fft)
+        except CheckFailed as e:            # the headline itself: no line at all (a broken kernel cannot post a number)
+            raise SystemExit(str(e))
         samples_per_step = float(N) * batch * world
         value = samples_per_step * args.steps / wall / 1e9
         alg_bytes = plan.algorithmic_bytes                      # per launch, this rank
@@ -614,6 +643,7 @@ def main():
                 "traffic": traffic[0] if traffic else None,
                 "traffic_source": traffic[1] if traffic else None,
                 "kernel_ms": kernel_ms,
+                "kernel_ms_per_rank": {"min": min(kernel_ms_per_rank), "max": max(kernel_ms_per_rank), "all": kernel_ms_per_rank},
                 "kernel_ms_single_launches": {"mean": single_mean, "sigma": single_sigma, "n": len(singles)},
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
@@ -627,31 +657,55 @@ def main():
             "device": torch.cuda.get_device_name(local_rank),
             "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none",
         }
-        if world == 1 and not args.no_other_configs and batch == BATCH:
+        if world == 1 and not args.no_other_configs and not args.only_dist_entry and batch == BATCH:
             x = y = None
             torch.cuda.empty_cache()
             line["other_configs"] = other_configs(torch, tf, orc, local_rank)
     else:
         line = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()          # (before the distributed entry: everything the line needs apart from that entry is then in hand)
     if (world > 1 or args.with_dist) and not args.no_other_configs:
-        # BASELINE configs[4b]: every rank takes part (one exchange per transform); rank 0 reports
+        # BASELINE configs[4b]: every rank takes part (one exchange per transform); rank 0 reports. Same failure policy as every
+        # other entry ({"error": ...}, line printed, exit code non-zero), plus a watchdog: this is the one entry that contains a
+        # collective no one-GPU box can rehearse with more than one rank, and a rank stuck inside it cannot be interrupted from Python.
+        # If the entry has not returned after --dist-timeout seconds, rank 0 prints the line it has (the headline is complete and
+        # self-checked by now) with the entry marked as timed out, and every rank leaves with exit code 3.
         x = y = None
         torch.cuda.empty_cache()
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line.setdefault("other_configs", {})["configs[4b]_n2^26_distributed"] = {
+                    "error": f"timed out after {args.dist_timeout} s (a rank is stuck inside the entry; the headline above is unaffected)"}
+                print(json.dumps(line), flush=True)
+            print(f"bench.py: rank {rank}: configs[4b] entry timed out after {args.dist_timeout} s", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        dog = threading.Timer(args.dist_timeout, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             rep = dist_2pow26(torch, tf, dist, rank, world, local_rank, self_via_comm=args.dist_self_via_comm)
         except Exception as e:      # noqa: BLE001  (the headline line must not depend on this entry)
             rep = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
         if rank == 0:
             if "error" in rep:
                 print("bench.py: configs[4b] entry: " + rep["error"], file=sys.stderr, flush=True)
             line.setdefault("other_configs", {})["configs[4b]_n2^26_distributed"] = rep
+    failed = []
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        failed = [k for k, v in line.get("other_configs", {}).items() if isinstance(v, dict) and "error" in v]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        # one policy for all side entries: the (self-checked) headline line has been printed, the failures are in it, the exit code says so
+        print("bench.py: failed other_configs entries: " + ", ".join(failed), file=sys.stderr, flush=True)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

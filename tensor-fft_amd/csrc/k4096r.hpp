@@ -29,13 +29,6 @@ namespace k4096r {
 
 using namespace k4096;
 
-// Fused 2D row pass (ROWS), placement of its 32 vector-memory instructions per wave and iteration (A/B knob while the
-// schedule is being settled): 0 = all 16 loads in one burst behind barrier B, all 16 stores in one burst after the read-back;
-// 1 = loads spread over the tiles of stages 1-3; 2 = also the stores: the spectrum is read back into registers, the regions are
-// released (barrier D) and the 16 stores go out one by one between the tiles of the NEXT iteration's front end.
-#ifndef TFFT_ROWS_SPREAD
-#define TFFT_ROWS_SPREAD 2
-#endif
 
 // (Tried: two independent 4-wave workgroups per CU with the G table read from global memory instead of LDS, so that one
 // workgroup computes while the other waits for memory: 2^13 487 -> 456 Gsamples/s, 2^14 435 -> 445; not kept.)
@@ -48,6 +41,15 @@ using namespace k4096;
 // stores it as row 512 s + r0 of the intermediate image. What remains is a radix-512 column pass over each block of
 // 512 rows (colfft512_wg_kernel) that writes rows 8 k' + s: two passes over HBM instead of three. `batch` then counts
 // workgroup iterations (images x 512) and the strides are per image.
+// Round 4, where this pass's time goes (phase clock of the measurement build, tools/exp_rows_phases.py, profiles/r4_rows_phases.txt;
+// cycles per iteration and wave, 31.5 k in all): front end 4.2 k, stages 1-3 5.8 k, and 10.5 k stalled at the ISSUE of the 16 loads
+// behind barrier B (waves 4-7: 16.6 k) plus 5.3 k at the 16 stores: the CU's memory pipeline accepts a 1-KiB wave instruction about
+// every 115 cycles and an in-order wave waits at the instruction (that is the 54 % SQ_WAIT_INST_ANY of the round-3 PMC run); the
+// input itself has long landed when the front end asks for it (160 cycles). Spreading the loads over the stage tiles and the
+// stores, held in registers, over the next front end (both built and A/B-ed in one process, bit-identical output) gives 0 % and
+// -3 %: profiles/r4_rows_same_box.txt. On ONE box: a plain copy with this pass's access pattern 1776 us, the same copy with this
+// loop's barriers and the arithmetic replaced by s_sleep (tools/rows2d_sched.hip) 1783 us, this kernel 1806 us. The pass runs at
+// the copy rate of its pattern; what round 3 read as 10 % of headroom was the box-to-box spread of that copy rate (1611-1776 us).
 template <int R, bool ROWS = false>
 __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                                uint16_t* out_re, uint16_t* out_im, Addr in_map,
@@ -144,23 +146,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         raw[j][jj] = ROWS ? *reinterpret_cast<const u4*>(src + 128 * j) : __builtin_nontemporal_load(reinterpret_cast<const u4*>(src + 128 * j));
     }
   };
-  constexpr int kSpread = ROWS ? TFFT_ROWS_SPREAD : 0;
-  // one of the 16 loads of an iteration: k = 4 j + jj -> raw[j][jj] (the order the front end consumes them in)
-  auto issue_load = [&](uint32_t it, int k) {
-    const int j = k >> 2, jj = k & 3;
-    const uint32_t b = it >> 9, r0 = it & 511;                           // (ROWS only)
-    const uint64_t base = in_map.off(b) + static_cast<uint64_t>(r0) * 4096;
-    const int rho = 4 * fg + jj;
-    const int h = rho / (2 * R), pl = (rho % (2 * R)) / R, i = rho % R;
-    const uint16_t* const src = (pl ? in_im : in_re) + base + 512ull * 4096 * i + 8u * (64u * (s * kPs + h) + fn);
-    raw[j][jj] = *reinterpret_cast<const u4*>(src + 128 * j);
-  };
   Rotor rot(blockIdx.x, gridDim.x);                       // (iteration order: k4096::Rotor)
   if (rot.item() < groups_total) issue_loads(rot.item());
-  // kSpread == 2: the previous iteration's spectrum, waiting in registers for its stores
-  u4 keep_re[8], keep_im[8];
-  uint16_t *keep_row_re = nullptr, *keep_row_im = nullptr;
-  bool have_keep = false;
 
   // output side of the front-end product: lane (g, n) holds rows rho' = 4 g + r: outputs s2a (r = 0, 1: re, im) and
   // s2a + 1 (r = 2, 3) of column set h'
@@ -241,26 +228,13 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       // keep the scheduler from pulling the next chunk's 8 products (32 accumulator registers) and twiddle chains up here:
       // with all 32 tiles in one scheduling region it spills
       __builtin_amdgcn_sched_barrier(0);
-      if (kSpread == 2 && have_keep) {
-        // four of the previous iteration's 16 row stores (rows of 1 KiB: 2 j, 2 j + 1 of both planes)
-#pragma unroll
-        for (int i2 = 2 * j; i2 < 2 * j + 2; ++i2) {
-          *reinterpret_cast<u4*>(keep_row_re + 512 * i2 + 8 * lane) = keep_re[i2];
-          *reinterpret_cast<u4*>(keep_row_im + 512 * i2 + 8 * lane) = keep_im[i2];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     TFFT_PHASE(1)
     __builtin_amdgcn_s_barrier();            // B: u_0 .. u_(R-1) are complete
     TFFT_PHASE(2)
     // the raw registers are free: the next iteration's input starts flying now
-    // (spread form: always issued, the last iteration re-reads its own rows, so that no load hangs under a condition)
-    const uint32_t nxt = rot.peek() < groups_total ? rot.peek() : it;
-    if (kSpread == 0) {
-      if (rot.peek() < groups_total) issue_loads(rot.peek());
-    }
+    if (rot.peek() < groups_total) issue_loads(rot.peek());
     TFFT_PHASE(3)
 
     // ---- stage 1 on this wave's own region, exactly the 4096 kernel's: D1_n1[k0 = 4g + r][n0 = lane & 15]
@@ -284,11 +258,6 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       for (int r = 0; r < 4; ++r) {
         pr[t][r] = pk(dre[0][r], dre[1][r]);
         pi[t][r] = pk(dim[0][r], dim[1][r]);
-      }
-      if (kSpread) {                                      // one load of the next iteration's input per tile pair
-        __builtin_amdgcn_sched_barrier(0);
-        issue_load(nxt, t);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // (the transposed reads above have returned before the staging stores below are issued: their data feeds the
@@ -336,11 +305,6 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
           ore[r2][kp] = pk(e_re[r2], o_re[r2]);
           oim[r2][kp] = pk(e_im[r2], o_im[r2]);
         }
-        if (kSpread) {
-          __builtin_amdgcn_sched_barrier(0);
-          issue_load(nxt, 8 + 4 * half + kp);
-          __builtin_amdgcn_sched_barrier(0);
-        }
       }
 #pragma unroll
       for (int r2 = 0; r2 < 4; ++r2) {
@@ -369,18 +333,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         const uint32_t rd = 16u * (lane ^ ((lane >> 3) & 1));
         const u4 vr = *reinterpret_cast<const u4*>(wl + 1024 * i + rd);
         const u4 vi = *reinterpret_cast<const u4*>(wl + 8192 + 1024 * i + rd);
-        if (kSpread == 2) {
-          keep_re[i] = vr;
-          keep_im[i] = vi;
-        } else {
-          *reinterpret_cast<u4*>(row_re + 512 * i + 8 * lane) = vr;
-          *reinterpret_cast<u4*>(row_im + 512 * i + 8 * lane) = vi;
-        }
-      }
-      if (kSpread == 2) {
-        keep_row_re = row_re;
-        keep_row_im = row_im;
-        have_keep = true;
+        *reinterpret_cast<u4*>(row_re + 512 * i + 8 * lane) = vr;
+        *reinterpret_cast<u4*>(row_im + 512 * i + 8 * lane) = vi;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       TFFT_PHASE(5)
@@ -441,13 +395,6 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // D: the staged spectra have been read; regions may be refilled
-  }
-  if (kSpread == 2 && have_keep) {             // the last iteration's spectrum
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      *reinterpret_cast<u4*>(keep_row_re + 512 * i + 8 * lane) = keep_re[i];
-      *reinterpret_cast<u4*>(keep_row_im + 512 * i + 8 * lane) = keep_im[i];
-    }
   }
 #ifdef TFFT_DEBUG_KERNELS
   if (stamps && lane == 0 && blockIdx.x < 256)

@@ -1,12 +1,12 @@
 """A/B of two builds of the library in separate processes on the same box: python tools/ab_lib.py LIBNAME N:batch ...
-(LIBNAME = file name under tensor-fft_amd/, e.g. a copy built from another revision as libtfft_old.so). 100 ms clock ramp,
+(LIBNAME = a library file, e.g. build/libtfft_old.so made by tools/build_ab.py from another revision). 100 ms clock ramp,
 median of 5 x 20 launches."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
 import tensor_fft_amd as tf
 from tensor_fft_amd import capi
-capi._LIB_NAME = sys.argv[1]
+capi._LIB_NAME = os.path.abspath(sys.argv[1])
 for spec in sys.argv[2:]:
     n, b = (int(v) for v in spec.split(":"))
     x = torch.empty(b * 2 * n, dtype=torch.float16, device="cuda"); tf.synth_uniform(x, x[n:], n, b)

@@ -1,6 +1,6 @@
 """A/B of plan options in ONE process, interleaved (box-to-box spread is +-4 %, so variants are only comparable inside a process):
     python tools/ab_variants.py N:batch[:inner] [lib=NAME:]VARIANT[,launch_iters] ... [--order transposed] [--reps 10] [--rounds 5]
-(lib=NAME: the build tensor-fft_amd/libtfft_NAME.so made by tools/build_ab.py instead of the shipped library)
+(lib=NAME: the build build/libtfft_NAME.so made by tools/build_ab.py instead of the shipped library)
 Prints per variant the median over rounds of the mean launch time, Gsamples/s and GB/s per pass."""
 import argparse
 import os
@@ -41,7 +41,7 @@ if args.shape.startswith("2d:"):
         sp = importlib.util.spec_from_file_location("capi_" + libname, path)
         m = importlib.util.module_from_spec(sp)
         sp.loader.exec_module(m)
-        m._LIB_NAME = f"libtfft_{libname}.so"
+        m._LIB_NAME = os.path.join(ROOT, "build", f"libtfft_{libname}.so")     # an absolute path wins over the package directory
         return m
 
     for spec in args.variants:
@@ -97,7 +97,7 @@ def capi_for(libname):
         sp = importlib.util.spec_from_file_location("capi_" + libname, path)
         m = importlib.util.module_from_spec(sp)
         sp.loader.exec_module(m)
-        m._LIB_NAME = f"libtfft_{libname}.so"
+        m._LIB_NAME = os.path.join(ROOT, "build", f"libtfft_{libname}.so")     # an absolute path wins over the package directory
         _capis[libname] = m
     return _capis[libname]
 

@@ -6,9 +6,9 @@ import torch
 import __graft_entry__ as g
 g.build()
 import tensor_fft_amd as tf
-if os.environ.get("TFFT_AB_LIB"):            # A/B of another build of the library (file name under tensor-fft_amd/)
+if os.environ.get("TFFT_AB_LIB"):            # A/B of another build of the library (path, e.g. build/libtfft_NAME.so)
     from tensor_fft_amd import capi
-    capi._LIB_NAME = os.environ["TFFT_AB_LIB"]
+    capi._LIB_NAME = os.path.abspath(os.environ["TFFT_AB_LIB"])
     capi._lib = None                            # (g.build() above has already loaded the default build)
 n = 4096
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
