@@ -150,15 +150,18 @@ def _rel_l2(got, exact):
     return float(np.linalg.norm(got - exact) / np.linalg.norm(exact))
 
 
-def check_transforms(torch, orc, y, n, batch, ids, first_fft=0, seed=SEED, perm=None, scale=1.0):
+def check_transforms(torch, orc, y, n, batch, ids, first_fft=0, seed=SEED, perm=None, scale=1.0, in_perm=None):
     """Sampled transforms of an output block ([fft RE | fft IM], stride 2 n) against the oracle's fp64 DFT/N of the
-    regenerated input. perm: index map of a transposed-order spectrum. Returns the worst rel-L2 error; raises beyond
-    the library's stated tolerance."""
+    regenerated input. perm: index map of a transposed-order spectrum; in_perm: the generated block was handed to the plan as
+    a transposed-order INPUT, i.e. the signal is block[in_perm]. Returns the worst rel-L2 error; raises beyond the library's
+    stated tolerance."""
     import numpy as np
 
     worst = 0.0
     for b in ids:
         re, im = orc.synth_uniform(n, 1, first_fft + b, seed)
+        if in_perm is not None:
+            re, im = np.ascontiguousarray(re[:, in_perm]), np.ascontiguousarray(im[:, in_perm])
         e_re, e_im = orc.dft64(re, im)
         exact = (e_re[0] + 1j * e_im[0]) * scale
         o = y[b * 2 * n:(b + 1) * 2 * n].cpu().numpy().astype(np.float64)
@@ -207,7 +210,8 @@ def other_configs(torch, tf, orc, device):
              ("n8192_x_32768", 8192, 1 << 15, "natural"), ("n65536_x_4096", 1 << 16, 1 << 12, "natural"),
              ("configs[2]_n2^20_x_1024", 1 << 20, 1024, "natural"),
              ("configs[2]_n2^20_x_1024_transposed_order", 1 << 20, 1024, "transposed"),
-             ("n2^24_x_16", 1 << 24, 16, "natural"), ("configs[4b]_single_gpu_n2^26_x_1", 1 << 26, 1, "natural"))
+             ("configs[2]_n2^20_x_1024_transposed_input", 1 << 20, 1024, "transposed_in"),
+             ("n2^24_x_16", 1 << 24, 16, "natural"), ("n2^24_x_16_transposed_input", 1 << 24, 16, "transposed_in"), ("configs[4b]_single_gpu_n2^26_x_1", 1 << 26, 1, "natural"))
     def guarded(name, fn):
         """One failure policy for every entry: a failed check or an exception becomes {"error": ...} under the entry's name, the
         other entries and the headline line are unaffected, and main() exits non-zero after printing the line."""
@@ -222,17 +226,21 @@ def other_configs(torch, tf, orc, device):
         x = torch.empty(b * 2 * n, dtype=torch.float16, device="cuda")
         tf.synth_uniform(x, x[n:], n, b, seed=SEED + n)
         y = torch.empty_like(x)
-        plan = tf.TfftPlan(n, b, device, preserve_input=True, output_order=order)
+        plan = tf.TfftPlan(n, b, device, preserve_input=True, output_order="transposed" if order == "transposed" else "natural",
+                           input_order="transposed" if order == "transposed_in" else "natural")
         ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
         if plan.workspace_bytes:
             plan.set_workspace(ws)
         ms = timed(lambda: plan.exec(x, x[n:], y, y[n:]))
-        perm = None
+        perm = in_perm = None
         if order == "transposed":
             n2 = tf.transposed_n2(n)
             perm = np.arange(n).reshape(n2, n // n2).T.reshape(-1)         # out[k1 n2 + k2] = X[k1 + n1 k2]
+        if order == "transposed_in":
+            n2 = tf.transposed_n2(n)
+            in_perm = np.arange(n).reshape(n // n2, n2).T.reshape(-1)      # x[k1 + n1 k2] = in[k1 n2 + k2]
         if n <= (1 << 24):
-            err = check_transforms(torch, orc, y, n, b, sorted({0, b - 1}), seed=SEED + n, perm=perm)
+            err = check_transforms(torch, orc, y, n, b, sorted({0, b - 1}), seed=SEED + n, perm=perm, in_perm=in_perm)
             check = f"transforms 0 and {b - 1} vs the fp64 oracle: rel-L2 {err:.2e}"
         else:
             # 2^26: the full fp64 oracle transform takes ~30 s of host time; check Parseval and 4 bins computed directly

@@ -30,10 +30,11 @@ constexpr int kFftsPerWave = 16;
 
 // in_*/out_*: planar binary16; transform b at +b*stride halves. tables: k4096::build_tables() blob
 // (uses the natural-order F operand forms and the w256 twiddle block).
+template <bool OTW = false>
 __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                              uint16_t* out_re, uint16_t* out_im, Addr in_map,
                                                              Addr out_map, uint32_t batch,
-                                                             const uint8_t* __restrict__ tables) {
+                                                             const uint8_t* __restrict__ tables, OutTw otw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -103,8 +104,18 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
       const u4 raw2 = {pk(t_re[0], t_re[1]), pk(t_re[2], t_re[3]), pk(t_im[0], t_im[1]), pk(t_im[2], t_im[3])};
       const h8 a2 = __builtin_bit_cast(h8, raw2);
       // stage 2: rows k0, slots n0  ->  D2[k0 = 4g + r][k1 = lane & 15]
-      const f4 o_re = mfma(a2, f_re);
-      const f4 o_im = mfma(a2, f_im);
+      f4 o_re = mfma(a2, f_re);
+      f4 o_im = mfma(a2, f_im);
+      if (OTW) {                       // transposed-input plan: output k = 4g + r + 16 k1 of row (b0 + t) & row_mask times w_N^(row k)
+        const uint32_t row = (b0 + static_cast<uint32_t>(t)) & otw.row_mask;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float vr = o_re[r], vi = o_im[r];
+          otw_apply(otw, row, 4u * g + r + 16u * x, vr, vi);
+          o_re[r] = vr;
+          o_im[r] = vi;
+        }
+      }
       // stage the spectrum in the transform's own (consumed) 1-KiB slot [RE 512 B | IM 512 B] ...
       const u2 vr = {pk(o_re[0], o_re[1]), pk(o_re[2], o_re[3])};
       const u2 vi = {pk(o_im[0], o_im[1]), pk(o_im[2], o_im[3])};

@@ -108,11 +108,11 @@ inline void build_tables(int R, std::vector<uint8_t>& blob, double fa = 1.0 / 16
 // in_*/out_*: planar binary16; transform b at +b*stride halves. tables: build_tables(R) blob.
 // STG: stage each transform's spectrum through its own (already consumed) LDS slot and store it as full 1-KiB rows with
 // non-temporal 16-byte stores, instead of 8-byte pieces straight from registers.
-template <int R, bool STG = true>
+template <int R, bool STG = true, bool OTW = false>
 __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                               uint16_t* out_re, uint16_t* out_im, Addr in_map,
                                                               Addr out_map, uint32_t batch,
-                                                              const uint8_t* __restrict__ tables) {
+                                                              const uint8_t* __restrict__ tables, OutTw otw) {
   constexpr int kPerWave = 16 / R;          // transforms per wave iteration
   constexpr int kPlane = 512 * R;           // bytes of one plane of one transform
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -245,6 +245,11 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
           v[r].im = __builtin_fmaf(o_re[r][reg], w_im[reg], o_im[r][reg] * w_re[reg]);
         }
         stockham::dft<R>(v);
+        if (OTW) {                     // transposed-input plan: output kk + 256 s of row (b0 + t) & row_mask times w_N^(row (kk + 256 s))
+          const uint32_t row = (b0 + static_cast<uint32_t>(t)) & otw.row_mask;
+#pragma unroll
+          for (int s = 0; s < R; ++s) otw_apply(otw, row, 4u * g + reg + 16u * x + 256u * s, v[s].re, v[s].im);
+        }
 #pragma unroll
         for (int s = 0; s < R; ++s) {
           if ((reg & 1) == 0) {

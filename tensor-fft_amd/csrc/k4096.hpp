@@ -95,6 +95,24 @@ struct Addr {
   }
 };
 
+// Output twiddle of the row transforms of a transposed-INPUT plan (tfft_plan_opts.input_order = TFFT_ORDER_TRANSPOSED, tfft.hip
+// create_transposed_in): the caller's block is the [N1][N2] matrix in[k1 N2 + k2] = x[k1 + N1 k2]; transform b of the row pass is
+// row k1 = b & row_mask of its matrix, and its output q must leave as  w_N^(k1 q) DFT_N2(row k1)[q]  so that one plain radix-N1
+// column pass over k1 finishes X[q + N2 p] in natural order (decimation in time; the four-step twiddle sits between the two
+// passes, and the only fp32 values between them are this kernel's final accumulators: no extra rounding). k1 q < N <= 2^24 is
+// exact in fp32; v_sin / v_cos take revolutions.
+struct OutTw {
+  uint32_t n_mask = 0, row_mask = 0;
+  float inv_n = 0.f;
+};
+__device__ __forceinline__ void otw_apply(const OutTw& t, uint32_t row, uint32_t q, float& re, float& im) {
+  const float a = static_cast<float>((row * q) & t.n_mask) * t.inv_n;
+  const float c = __builtin_amdgcn_cosf(a), s = -__builtin_amdgcn_sinf(a);
+  const float r = __builtin_fmaf(re, c, -(im * s));
+  im = __builtin_fmaf(re, s, im * c);
+  re = r;
+}
+
 // ---------------------------------------------------------------------------
 // host: constant operands
 // ---------------------------------------------------------------------------
@@ -316,10 +334,10 @@ __device__ __forceinline__ void st(uint16_t* p, u4 v) {
 }
 
 // in_*/out_*: planar binary16; FFT b at +b*stride halves. tables: build_tables() blob.
-template <int V>
+template <int V, bool OTW = false>
 __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
     const uint16_t* in_re, const uint16_t* in_im, uint16_t* out_re, uint16_t* out_im, Addr in_map,
-    Addr out_map, uint32_t batch, const uint8_t* __restrict__ tables) {
+    Addr out_map, uint32_t batch, const uint8_t* __restrict__ tables, OutTw otw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -471,6 +489,16 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       const u4 hraw = *reinterpret_cast<const u4*>(h_tab + k0 * 1024);
       o_re = mfma(__builtin_bit_cast(h8, hraw), bop);   // o[r2] = X[k0 + 16 k1 + 256 (4g + r2)]
       o_im = mfma(im_form(hraw), bop);
+      if (OTW) {
+        const uint32_t row = b & otw.row_mask;
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {
+          float vr = o_re[r2], vi = o_im[r2];
+          otw_apply(otw, row, k0 + 16u * (lane & 15) + 256u * (4 * g + r2), vr, vi);
+          o_re[r2] = vr;
+          o_im[r2] = vi;
+        }
+      }
     };
 #pragma unroll
     for (int half = 0; half < 2; ++half) {

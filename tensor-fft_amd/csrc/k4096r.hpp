@@ -50,11 +50,11 @@ using namespace k4096;
 // -3 %: profiles/r4_rows_same_box.txt. On ONE box: a plain copy with this pass's access pattern 1776 us, the same copy with this
 // loop's barriers and the arithmetic replaced by s_sleep (tools/rows2d_sched.hip) 1783 us, this kernel 1806 us. The pass runs at
 // the copy rate of its pattern; what round 3 read as 10 % of headroom was the box-to-box spread of that copy rate (1611-1776 us).
-template <int R, bool ROWS = false>
+template <int R, bool ROWS = false, bool OTW = false>
 __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                                uint16_t* out_re, uint16_t* out_im, Addr in_map,
                                                                Addr out_map, uint32_t batch,
-                                                               const uint8_t* __restrict__ tables
+                                                               const uint8_t* __restrict__ tables, OutTw otw
 #ifdef TFFT_DEBUG_KERNELS
                                                                , unsigned long long* stamps   // tools/exp_rows_phases.py; null in normal use
 #endif
@@ -291,6 +291,16 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       const u4 hraw = *reinterpret_cast<const u4*>(h_tab + k0 * 1024);
       o_re = mfma(__builtin_bit_cast(h8, hraw), bop);   // o[r2] = U_s[k0 + 16 k1 + 256 (4g + r2)]
       o_im = mfma(im_form(hraw), bop);
+      if (OTW) {                       // transposed-input plan: output R kk + s of row b & row_mask times w_N^(row (R kk + s))
+        const uint32_t row = b & otw.row_mask;
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {
+          float vr = o_re[r2], vi = o_im[r2];
+          otw_apply(otw, row, static_cast<uint32_t>(R) * (k0 + 16u * (lane & 15) + 256u * (4 * g + r2)) + s, vr, vi);
+          o_re[r2] = vr;
+          o_im[r2] = vi;
+        }
+      }
     };
 #pragma unroll
     for (int half = 0; half < 2; ++half) {

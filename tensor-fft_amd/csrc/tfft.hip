@@ -127,6 +127,8 @@ struct InternalOpts {
   // segments of in_seg_len contiguous halves, in_seg_stride apart; in_batch_stride is then the distance between the first
   // segments of consecutive transforms (< n). Only plans whose first pass is a cooperative radix-256 / 512 column pass.
   uint64_t in_seg_len = 0, in_seg_stride = 0;
+  // row pass of a transposed-INPUT plan (create_transposed_in): output q of row k1 = b & (2^group_shift - 1) times w_otw_n^(k1 q)
+  uint64_t otw_n = 0;
 };
 
 }  // namespace
@@ -148,12 +150,16 @@ struct tfft_plan {
   // then built for M instead of n
   uint64_t tw4_modulus = 0, tw4_col0 = 0;
   k4096::Addr in_map{}, out_map{};       // single-kernel plans: where transform b starts (plain or grouped)
+  k4096::OutTw otw{};                    // single-kernel plans: output twiddle of a transposed-input plan's row pass (n_mask = 0: off)
+  // TFFT_ORDER_TRANSPOSED input: contiguous N2-point row pass (with that output twiddle) into the workspace, then ONE plain
+  // radix-N1 column pass out of it; sub_row / sub_col below, run in this order
   uint32_t in_seg_shift = 31;            // segmented input rows of the first column pass (colfft::Args::in_seg_*; 31 / 0 = off)
   uint64_t in_seg_gap = 0;
   // TFFT_ORDER_TRANSPOSED: strided radix-N1 column pass (with the four-step twiddle) into the workspace, then N1 * batch
   // contiguous N2-point transforms out of it; this plan then only owns the two sub-plans and the workspace
   tfft_plan* sub_col = nullptr;
   tfft_plan* sub_row = nullptr;
+  bool rows_first = false;
   void* d_tables = nullptr;     // k4096::build_tables blob (K4096 and Col256 passes)
   float2* d_tw_lo = nullptr;    // w_n tables (Col256 and Stockham passes)
   float2* d_tw_hi = nullptr;
@@ -340,10 +346,19 @@ int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, voi
   static const uint32_t iters_env = env_iters("TFFT_K4096_ITERS", 0);   // experiment knob (debug build only)
   const uint32_t iters = iters_env ? iters_env : plan_iters(p->launch_iters, blocks_needed >= 4u * static_cast<uint32_t>(p->num_cus) ? 2u : 1u);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, iters);
-  TFFT_LAUNCH(k4096::fft4096_kernel<V>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+  if constexpr (V == (k4096::kStageOut | k4096::kNonTemporal)) {
+    if (p->otw.n_mask) {       // row pass of a transposed-input plan (default variant only, create_transposed_in)
+      TFFT_LAUNCH((k4096::fft4096_kernel<V, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+                         static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                         static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                         static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
+      return TFFT_OK;
+    }
+  }
+  TFFT_LAUNCH((k4096::fft4096_kernel<V, false>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
+                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
   return TFFT_OK;
 }
 
@@ -353,10 +368,16 @@ int launch_k256(const tfft_plan* p, const void* in_re, const void* in_im, void* 
   const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
   static const uint32_t iters_dflt = env_iters("TFFT_K256_ITERS", 2);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
-  TFFT_LAUNCH(k256::fft256_kernel, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
-                     static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
-                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
+  if (p->otw.n_mask)
+    TFFT_LAUNCH(k256::fft256_kernel<true>, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
+                       static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                       static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                       static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
+  else
+    TFFT_LAUNCH(k256::fft256_kernel<false>, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
+                       static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                       static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                       static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
   return TFFT_OK;
 }
 
@@ -367,10 +388,19 @@ int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, voi
   const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
   static const uint32_t iters_dflt = env_iters("TFFT_K256_ITERS", 2);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
-  TFFT_LAUNCH((k256r::fft256r_kernel<R, STG>), dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
+  if constexpr (STG) {
+    if (p->otw.n_mask) {       // row pass of a transposed-input plan (staged stores only, create_transposed_in)
+      TFFT_LAUNCH((k256r::fft256r_kernel<R, true, true>), dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
+                         static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                         static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                         static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
+      return TFFT_OK;
+    }
+  }
+  TFFT_LAUNCH((k256r::fft256r_kernel<R, STG, false>), dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables));
+                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
   return TFFT_OK;
 }
 
@@ -399,14 +429,22 @@ int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, vo
   // kernel does not help here (measured at 2^13: 405 / 425 / 440 / 457 Gsamples/s for 1 / 2 / 4 / all iterations)
   static const uint32_t iters_dflt = env_iters("TFFT_K4096R_ITERS", 1000000);   // experiment knob (debug build only)
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
-  TFFT_LAUNCH(k4096r::fft4096r_kernel<R>, dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
-                     static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
-                     static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables)
 #ifdef TFFT_DEBUG_KERNELS
-                     , static_cast<unsigned long long*>(nullptr)
+#define TFFT_NO_STAMPS , static_cast<unsigned long long*>(nullptr)
+#else
+#define TFFT_NO_STAMPS
 #endif
-                     );
+  if (p->otw.n_mask)           // row pass of a transposed-input plan
+    TFFT_LAUNCH((k4096r::fft4096r_kernel<R, false, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+                       static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                       static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                       static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw TFFT_NO_STAMPS);
+  else
+    TFFT_LAUNCH((k4096r::fft4096r_kernel<R, false, false>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
+                       static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
+                       static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
+                       static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw TFFT_NO_STAMPS);
+#undef TFFT_NO_STAMPS
   return TFFT_OK;
 }
 
@@ -431,7 +469,7 @@ int launch_rows2d(const tfft_plan* p, const void* in_re, const void* in_im, void
   TFFT_LAUNCH((k4096r::fft4096r_kernel<8, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), k4096::Addr{image_stride, image_stride, 0, 0},
-                     k4096::Addr{image_stride, image_stride, 0, 0}, iterations, static_cast<const uint8_t*>(p->d_tables)
+                     k4096::Addr{image_stride, image_stride, 0, 0}, iterations, static_cast<const uint8_t*>(p->d_tables), k4096::OutTw{}
 #ifdef TFFT_DEBUG_KERNELS
                      , stamps
 #endif
@@ -746,6 +784,13 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
       w = static_cast<_Float16*>(p->ws);
     }
     _Float16* const w_im = w + p->batch * p->n;
+    if (p->rows_first) {
+      // transposed-order INPUT: N1 contiguous N2-point transforms per [N1][N2] block (output twiddle w_N^(k1 q) in their epilogue)
+      // into the workspace, then one radix-N1 column pass over k1 writes X[q + N2 p] in natural order
+      int rc = launch_chain(p->sub_row, in_re, in_im, w, w_im, s);
+      if (rc) return rc;
+      return launch_chain(p->sub_col, w, w_im, out_re, out_im, s);
+    }
     int rc = launch_chain(p->sub_col, in_re, in_im, w, w_im, s);
     if (rc) return rc;
     return launch_chain(p->sub_row, w, w_im, out_re, out_im, s);
@@ -1042,6 +1087,50 @@ int normalise_opts(const tfft_plan_opts* opts, tfft_plan_opts* o) {
   return TFFT_OK;
 }
 
+int create_transposed_in(tfft_plan* p, int device_id) {
+  // N = N1 N2 as for the transposed OUTPUT order. The caller's block holds in[k1 N2 + k2] = x[k1 + N1 k2]: N1 rows, row k1 the
+  // decimated sequence x[k1 + N1 .]. Decimation in time:  X[q + N2 p] = sum_k1 w_N1^(k1 p) [ w_N^(k1 q) DFT_N2(row k1)[q] ].
+  // Pass 1: batch * N1 contiguous N2-point transforms (single-pass kernels, grouped addressing, the bracket's twiddle applied to
+  // their fp32 accumulators) into the planar workspace [RE: batch x N | IM: batch x N]; pass 2: one plain radix-N1 column pass
+  // along k1 (N2 columns) from it into `out`, whose row p, column q is X[q + N2 p]: natural order.
+  const uint64_t n = p->n, n2 = tfft_plan_transposed_n2(n), n1 = n / n2;
+  if (p->batch * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "batch * N1 too large for one launch");
+  if (p->scale_mode == TFFT_SCALE_ONCE)
+    return fail(TFFT_ERR_ARG, "TFFT_SCALE_ONCE is not available with transposed-order input: the plan's last fp32 multiply lies in "
+                              "front of its last stage (use TFFT_SCALE_SEQUENTIAL or TFFT_SCALE_NONE)");
+  constexpr int kColBits = 262144 | 524288;
+  if (p->variant & ~kColBits)
+    return fail(TFFT_ERR_ARG, "tfft_plan_opts.variant " + std::to_string(p->variant) + ": a plan with transposed-order input honours only the "
+                              "column-pass bits 262144 / 524288");
+  tfft_plan_opts ro = TFFT_PLAN_OPTS_INIT;
+  ro.in_batch_stride = n2;
+  ro.out_batch_stride = n2;
+  ro.preserve_input = 1;
+  ro.scale = p->scale_mode;
+  ro.launch_iters = p->launch_iters;
+  InternalOpts ri;
+  ri.group_shift = static_cast<uint32_t>(ilog2(n1));
+  ri.in_gstride = p->in_stride;            // the rows of one transform sit N2 apart inside the caller's [RE | IM] block
+  ri.out_gstride = n;                      // planar workspace: row b at b * N2 either way
+  ri.otw_n = n;
+  int rc = create_plan(n2, p->batch * n1, device_id, &ro, ri, &p->sub_row);
+  if (rc) return rc;
+  tfft_plan_opts co = TFFT_PLAN_OPTS_INIT;
+  co.in_batch_stride = n;
+  co.out_batch_stride = p->out_stride;
+  co.inner = n2;
+  co.preserve_input = 1;
+  co.scale = p->scale_mode;
+  co.launch_iters = p->launch_iters;
+  co.variant = (p->variant & kColBits) | (n1 == 512 ? 67108864 : 0);
+  rc = create_plan(n1, p->batch, device_id, &co, InternalOpts{}, &p->sub_col);
+  if (rc) return rc;
+  if (p->sub_col->passes.size() != 1 || p->sub_col->passes[0].kind != PassKind::Col256)
+    return fail(TFFT_ERR_ARG, "transposed-order input: the column transform of this length does not plan as one pass");
+  p->rows_first = true;
+  return TFFT_OK;
+}
+
 int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* caller_opts, const InternalOpts& io, tfft_plan** out) {
   g_err.clear();
   if (!out) return fail(TFFT_ERR_ARG, "null plan pointer");
@@ -1068,6 +1157,16 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   if (order != TFFT_ORDER_NATURAL && order != TFFT_ORDER_TRANSPOSED) return fail(TFFT_ERR_ARG, "unknown tfft_plan_opts.output_order");
   if (order == TFFT_ORDER_TRANSPOSED && inner > 1)
     return fail(TFFT_ERR_ARG, "TFFT_ORDER_TRANSPOSED exists for a contiguous axis only (inner <= 1)");
+  const int in_order = opts->input_order;
+  if (in_order != TFFT_ORDER_NATURAL && in_order != TFFT_ORDER_TRANSPOSED) return fail(TFFT_ERR_ARG, "unknown tfft_plan_opts.input_order");
+  if (in_order == TFFT_ORDER_TRANSPOSED) {
+    if (inner > 1) return fail(TFFT_ERR_ARG, "TFFT_ORDER_TRANSPOSED exists for a contiguous axis only (inner <= 1)");
+    if (order == TFFT_ORDER_TRANSPOSED)
+      return fail(TFFT_ERR_ARG, "input_order and output_order cannot both be TFFT_ORDER_TRANSPOSED (one side of a plan is in natural order)");
+    if (!tfft_plan_transposed_n2(n))
+      return fail(TFFT_ERR_ARG, "input_order = TFFT_ORDER_TRANSPOSED: this length has no [N1][N2] layout (2^16 <= N <= 2^24, tfft_plan_transposed_n2)");
+    if (opts->fourstep_n) return fail(TFFT_ERR_ARG, "fourstep_n and TFFT_ORDER_TRANSPOSED exclude each other");
+  }
   const uint64_t tw4 = opts ? opts->fourstep_n : 0;
   if (tw4) {
     if (!is_pow2(tw4) || tw4 < n || (n != 256 && n != 512) || inner < 64)
@@ -1118,9 +1217,23 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
     *out = p;
     return TFFT_OK;
   }
+  if (in_order == TFFT_ORDER_TRANSPOSED) {
+    rc = create_transposed_in(p, device_id);
+    if (rc) return bail(rc);
+    (void)hipSetDevice(prev);
+    *out = p;
+    return TFFT_OK;
+  }
   // ---- pass list (plan_passes: pure host logic, also behind tfft_plan_describe)
   plan_passes(n, inner, pvariant, p->passes);
   if (io.group_shift && !single_kernel(p)) return bail(fail(TFFT_ERR_ARG, "grouped addressing needs a single-kernel plan"));
+  if (io.otw_n) {
+    if (!single_kernel(p) || (pvariant & ~0) != 0 || io.otw_n > (uint64_t{1} << 24))
+      return bail(fail(TFFT_ERR_ARG, "output twiddle: needs a single-kernel row plan with the default variant and N <= 2^24"));
+    p->otw.n_mask = static_cast<uint32_t>(io.otw_n - 1);
+    p->otw.row_mask = (1u << io.group_shift) - 1u;
+    p->otw.inv_n = 1.0f / static_cast<float>(io.otw_n);
+  }
   if (tw4 && !(p->passes.size() == 1 && p->passes[0].kind == PassKind::Col256))
     return bail(fail(TFFT_ERR_ARG, "fourstep_n: this (n, inner) does not plan as one column pass"));
   if (io.in_seg_len) {

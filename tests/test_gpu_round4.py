@@ -177,3 +177,98 @@ def test_bench_distributed_entry_rehearsal_with_one_rank():
     assert all(ph[k]["max_over_ranks"] > 0 for k in ("pre_ms", "exchange_ms", "post_ms"))
     assert e["bytes_through_the_collective_per_rank"] == 2 * (1 << 26) * 2            # both planes of the own chunk
     assert "Parseval" in e["check"]
+
+
+# ---- transposed-order INPUT (tfft_plan_opts.input_order): in[k1 N2 + k2] = x[k1 + N1 k2] -> natural-order X
+def _transposed_layout(x, n1, n2):
+    """natural-order samples -> the [N1][N2] matrix in[k1 N2 + k2] = x[k1 + N1 k2]"""
+    return np.ascontiguousarray(x.reshape(n2, n1).T).reshape(-1)
+
+
+@pytest.mark.parametrize("lg", list(range(16, 25)))
+@pytest.mark.parametrize("scale", ["sequential", "none"])
+def test_transposed_input_against_the_oracle(tf, orc, lg, scale):
+    """Two passes (contiguous N2-point transforms with the four-step twiddle in their fp32 epilogue, one radix-N1 column pass)
+    from the transposed layout to the natural-order spectrum, for every length that has the layout, against the fp64 oracle."""
+    import torch
+
+    n = 1 << lg
+    n2 = tf.transposed_n2(n)
+    n1 = n // n2
+    batch = max(2, min(8, (1 << 22) // n))
+    amp = 1.0 if scale == "sequential" else 40000.0 / n          # unscaled: keep N * max|x| inside binary16
+    re, im = orc.synth_uniform(n, batch, 0, lg)
+    re, im = (re * amp).astype(np.float16), (im * amp).astype(np.float16)
+    host = np.empty((batch, 2, n), dtype=np.float16)
+    for b in range(batch):
+        host[b, 0] = _transposed_layout(re[b], n1, n2)
+        host[b, 1] = _transposed_layout(im[b], n1, n2)
+    x = torch.from_numpy(host.reshape(-1)).cuda()
+    y = torch.full_like(x, float("nan"))
+    plan = tf.TfftPlan(n, batch, 0, input_order="transposed", scale=scale, preserve_input=True)
+    assert plan.num_launches == 2
+    keep = x.clone()
+    plan.exec(x, x[n:], y, y[n:])
+    torch.cuda.synchronize()
+    assert bool((x.view(torch.int16) == keep.view(torch.int16)).all())            # preserve_input
+    e_re, e_im = orc.dft64(re, im)
+    got = y.cpu().numpy().reshape(batch, 2, n).astype(np.float64)
+    f = 1.0 if scale == "sequential" else float(n)
+    for b in range(batch):
+        g, ex = got[b, 0] + 1j * got[b, 1], (e_re[b] + 1j * e_im[b]) * f
+        assert np.linalg.norm(g - ex) / np.linalg.norm(ex) <= REL_L2_TOL, (lg, scale, b)
+    # in place too (the input is consumed completely by the first pass before the second writes)
+    plan2 = tf.TfftPlan(n, batch, 0, input_order="transposed", scale=scale)
+    plan2.exec(x, x[n:], x, x[n:])
+    torch.cuda.synchronize()
+    assert bool((x.view(torch.int16) == y.view(torch.int16)).all())
+
+
+@pytest.mark.parametrize("lg", [16, 20, 21, 24])
+def test_spectrum_multiply_and_back_in_two_plus_two_passes(tf, orc, lg):
+    """What the transposed orders are for: forward (natural -> transposed spectrum, 2 passes), pointwise work on the spectrum in
+    that layout, inverse from it (transposed input -> natural samples, 2 passes): a circular shift by one sample done in the
+    frequency domain, checked against numpy's roll of the input."""
+    import torch
+
+    n = 1 << lg
+    n2 = tf.transposed_n2(n)
+    n1 = n // n2
+    rng = np.random.default_rng(lg)
+    xr, xi = rng.uniform(-1, 1, n).astype(np.float16), rng.uniform(-1, 1, n).astype(np.float16)
+    x = torch.from_numpy(np.concatenate([xr, xi])).cuda()
+    spec = torch.empty_like(x)
+    # forward unscaled (white noise of rms 0.58: |X| ~ 0.8 sqrt(N) <= 3300, inside binary16), inverse with the 1/N: x comes back
+    fwd = tf.TfftPlan(n, 1, 0, output_order="transposed", scale="none", preserve_input=True)       # X in the [N1][N2] layout
+    inv = tf.TfftPlan(n, 1, 0, input_order="transposed", preserve_input=True)                      # (1/N) sum X e^{+...}
+    assert fwd.num_launches == 2 and inv.num_launches == 2
+    fwd.exec(x, x[n:], spec, spec[n:])
+    # multiply bin k by exp(-2 pi i k / N) (a delay of one sample); bin k = k1 + N1 k2 sits at [k1][k2]
+    k = (torch.arange(n1, device="cuda", dtype=torch.float64)[:, None] + n1 * torch.arange(n2, device="cuda", dtype=torch.float64)[None, :]).reshape(-1)
+    ph = -2.0 * np.pi * k / n
+    c, s = torch.cos(ph), torch.sin(ph)
+    sr, si = spec[:n].double(), spec[n:].double()
+    prod = torch.cat([(sr * c - si * s), (sr * s + si * c)]).half()
+    back = torch.empty_like(x)
+    inv.exec_inverse(prod, prod[n:], back, back[n:])
+    torch.cuda.synchronize()
+    got = back.cpu().numpy().astype(np.float64)
+    want = np.concatenate([np.roll(xr.astype(np.float64), 1), np.roll(xi.astype(np.float64), 1)])
+    err = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert err < 3e-3, (lg, err)                                  # two transforms + one extra rounding of the product
+
+
+def test_transposed_input_refusals(tf):
+    with pytest.raises(tf.TfftError) as e:
+        tf.TfftPlan(1 << 15, 4, 0, input_order="transposed")
+    assert e.value.code == 5 and "no [N1][N2] layout" in e.value.message
+    with pytest.raises(tf.TfftError) as e:
+        tf.TfftPlan(1 << 20, 4, 0, input_order="transposed", output_order="transposed")
+    assert "cannot both" in e.value.message
+    with pytest.raises(tf.TfftError) as e:
+        tf.TfftPlan(1 << 20, 4, 0, input_order="transposed", scale="once")
+    assert "TFFT_SCALE_ONCE" in e.value.message
+    with pytest.raises(tf.TfftError):
+        tf.TfftPlan(1 << 20, 4, 0, input_order="transposed", variant=32)
+    with pytest.raises(tf.TfftError):
+        tf.TfftPlan(1 << 12, 4, 0, inner=64, input_order="transposed")

@@ -1,5 +1,11 @@
 """One named workload, a few back-to-back executions: the command rocprofv3 wraps when collecting kernel traces and
-PMC counters for a kernel other than the headline one (python3 tools/prof_workload.py NAME [reps]).
+PMC counters for a kernel other than the headline one (python3 tools/prof_workload.py NAME [reps [warmup]]).
+
+STEADY STATE: the `reps` counted executions follow `warmup` untimed ones (default 120: >= 200 ms of work for every workload here,
+what bench.py's other_configs run before they time, bench.py:171-193). A GPU that has idled needs that long to reach its clocks
+(profiles/r3_c2_per_dispatch.txt: 1.63, 2.11, 1.91, 1.79 ... ms before 1.56 for good); round 3's summaries averaged over that
+transient. tools/steady_stats.py and tools/summarize_pmc.py --skip drop the warm-up dispatches (the first warmup / (warmup + reps)
+of every kernel's dispatches) from what they fold.
 
     c1      BASELINE configs[1]   4096 x 65536                    (fft4096_kernel)
     c2      BASELINE configs[2]   2^20 x 1024                     (colfft256_wg_kernel x2 + tail)
@@ -23,6 +29,7 @@ import tensor_fft_amd as tf
 
 name = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 120
 
 
 def run1d(n, b, **kw):
@@ -32,10 +39,12 @@ def run1d(n, b, **kw):
     ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
     if plan.workspace_bytes:
         plan.set_workspace(ws)
-    for _ in range(reps):
+    for i in range(warmup + reps):
         plan.exec(x, x[n:], y, y[n:])
+        if i % 16 == 15:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
-    print(f"{name}: N={n} batch={b} passes={plan.num_launches} x{reps}")
+    print(f"{name}: N={n} batch={b} passes={plan.num_launches} warmup={warmup} reps={reps}")
 
 
 if name == "c1":
@@ -50,10 +59,13 @@ elif name == "c3":
     im = ((torch.rand(b * n * n, device="cuda") * 2 - 1)).half()
     o_re, o_im = torch.empty_like(re), torch.empty_like(im)
     plan = tf.TfftPlan2D(n, n, b, 0)
-    for _ in range(reps):
+    plan.set_workspace(torch.empty(plan.workspace_bytes // 2, dtype=torch.float16, device="cuda"))
+    for i in range(warmup + reps):
         plan.exec(re, im, o_re, o_im)
+        if i % 16 == 15:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
-    print(f"{name}: 2D 4096x4096 x{b} passes={plan.num_launches} x{reps}")
+    print(f"{name}: 2D 4096x4096 x{b} passes={plan.num_launches} warmup={warmup} reps={reps}")
 elif name.startswith("n"):
     f = name[1:].split(":")
     n = (1 << int(f[0][2:])) if f[0].startswith("2^") else int(f[0])

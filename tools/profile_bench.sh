@@ -2,8 +2,11 @@
 # rocprofv3 evidence for the headline benchmark, from the SAME command the driver runs (python3 bench.py):
 #   kernel trace + stats of a default run, then PMC counters in separate passes (FETCH_SIZE and WRITE_SIZE cannot share
 #   one; never --pmc together with a trace domain).   usage: tools/profile_bench.sh TAG
-# Output under gpurun_out/; fold with:  python tools/summarize_pmc.py TAG fft4096_kernel --dirs "gpurun_out/pmc_TAG_bench_*" \
-#   --trace "gpurun_out/trace_TAG_bench/*kernel_stats.csv" --alg-bytes 2147483648
+# Output under gpurun_out/; fold with (steady state only: the trace run issues 200 cold + 100 ramp + 20 warm-up launches in front
+# of its 200 timed + 20 single ones, a PMC pass 3 + 100 + 1 in front of 3 + 20):
+#   python tools/steady_stats.py "gpurun_out/trace_TAG_bench/*kernel_trace.csv" --only fft4096_kernel --skip 320 --out profiles/TAG_bench_kernel_stats.csv
+#   python tools/summarize_pmc.py TAG fft4096_kernel --dirs "gpurun_out/pmc_TAG_bench_*" --skip-frac 0.82 \
+#          --trace profiles/TAG_bench_kernel_stats.csv --alg-bytes 2147483648
 set -eo pipefail
 TAG=$1
 cd "$(dirname "$0")/.."

@@ -23,6 +23,9 @@ ap.add_argument("needles", nargs="*", default=["fft4096_kernel"])
 ap.add_argument("--dirs", default=None)
 ap.add_argument("--alg-bytes", type=float, default=0.0, help="algorithmic HBM bytes per dispatch of the (first) kernel")
 ap.add_argument("--trace", default=None, help="kernel-trace stats CSV to take average durations from")
+ap.add_argument("--skip-frac", type=float, default=0.0,
+                help="fraction of every kernel's dispatches (per counter, in dispatch order) that were warm-up executions of the profiled "
+                     "command and are dropped: warmup / (warmup + reps) of tools/prof_workload.py")
 args = ap.parse_args()
 pattern = args.dirs or os.path.join(ROOT, "gpurun_out", f"pmc_{args.tag}_*")
 dirs = sorted(glob.glob(pattern)) or sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_*")))
@@ -46,10 +49,16 @@ def summarize(needle):
     names = set()
     for row in rows:
         if needle in row["Kernel_Name"]:
-            vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            vals[(row["Counter_Name"], row["Kernel_Name"])].append((int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"])))
             names.add(row["Kernel_Name"])
+    steady = collections.defaultdict(list)
+    for (counter, _), v in vals.items():            # steady state only: drop each kernel's warm-up dispatches
+        v.sort()
+        steady[counter].extend(x for _, x in v[int(len(v) * args.skip_frac):])
+    vals = steady
     mean = {k: sum(v) / len(v) for k, v in vals.items()}
     out = {"kernel": needle, "kernel_names": sorted(names), "dispatches_per_counter": {k: len(v) for k, v in vals.items()},
+           "warmup_fraction_dropped": args.skip_frac,
            "mean_per_dispatch": mean}
     if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
         rd = mean["FETCH_SIZE"] * 1024 * 2
