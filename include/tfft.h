@@ -150,8 +150,9 @@ typedef struct tfft_plan_opts {
                            work); TFFT_LAUNCH_PERSISTENT: one workgroup per CU for the whole batch. Never changes results (the
                            kernels stride over the batch): the best shape at batch 65536 is not the best at batch 64. */
   int input_order;      /* TFFT_ORDER_* below; 0 = natural order. TFFT_ORDER_TRANSPOSED: the input is the [N1][N2] matrix
-                           in[k1 * N2 + k2] = x[k1 + N1 * k2] that a TRANSPOSED-output plan of the same length leaves behind
-                           (see there), and the result is in natural order: two passes over HBM for 2^16 <= N <= 2^24 */
+                           that a TRANSPOSED-output plan of the same length leaves behind (read as samples:
+                           in[k1 * N2 + k2] = x[k1 + N1 * k2]), and the result is in natural order: two passes over HBM for
+                           2^16 <= N <= 2^24 (see TFFT_ORDER_* below) */
 } tfft_plan_opts;
 enum { TFFT_LAUNCH_PERSISTENT = 65535 };
 /* Zero-initialised options that carry the compile-time size: `tfft_plan_opts o = TFFT_PLAN_OPTS_INIT;` */
@@ -176,19 +177,27 @@ int tfft_plan_opts_known_size(size_t bytes);
  *               stages in front of the scaling step can overflow when 16^s * max|x| > 65504 (s = stages before it). */
 enum { TFFT_SCALE_SEQUENTIAL = 0, TFFT_SCALE_NONE = 1, TFFT_SCALE_ONCE = 2 };
 
-/* tfft_plan_opts.output_order.
+/* tfft_plan_opts.output_order / input_order.
  *   NATURAL      out[k] = X[k] (what the reference produces, TensorRadix16.cu:169-213).
  *   TRANSPOSED   N = N1 * N2 (N2 = tfft_plan_transposed_n2(n), N1 = N / N2): out[k1 * N2 + k2] = X[k1 + N1 * k2], i.e.
  *                the [N1][N2] matrix of the four-step algorithm left un-transposed (the order DistributedFFT1D's
  *                "transposed" layout has). For 2^16 <= N <= 2^24 this takes TWO passes over HBM (one strided radix-N1
  *                column pass that also applies w_N^(k1 n2), one contiguous N2-point pass) where natural order needs
  *                three from 2^21 on (2^16 .. 2^20 take two passes either way): for callers that only reduce over the
- *                spectrum or index it through the map above. There is no transposed-order INPUT: tfft_exec_inverse on
- *                such a plan takes natural-order input like any other plan, so "multiply spectra and transform back"
- *                still needs natural order. Contiguous axis only (inner > 1 is refused). Lengths without a two-pass
+ *                spectrum, index it through the map above, or work on it pointwise and transform back with a plan whose
+ *                INPUT order is TRANSPOSED. Contiguous axis only (inner > 1 is refused). Lengths without a two-pass
  *                split fall back to NATURAL (tfft_plan_transposed_n2(n) == 0). variant: only the column-pass bits
  *                262144 / 524288 and the single-kernel bits of the N2 kernel (1 / 2 / 8 / 16, 1048576) are honoured,
  *                others are refused. Needs a workspace (tfft_plan_workspace_bytes). */
+/*   input_order = TRANSPOSED (same N1, N2): the input block is that same [N1][N2] matrix, in[k1 * N2 + k2] = x[k1 + N1 * k2], and
+ *                the result is in NATURAL order: N1 contiguous N2-point transforms whose fp32 epilogue applies the four-step
+ *                twiddle w_N^(k1 q), then ONE radix-N1 column pass (decimation in time) = two passes over HBM for
+ *                2^16 <= N <= 2^24. With tfft_exec_inverse on such a plan, "forward into the transposed order, multiply
+ *                spectra pointwise, transform back" costs 2 + 2 passes where natural order needs 3 + 3 from 2^21 on.
+ *                Lengths without the layout are refused (TFFT_ERR_ARG), as are TRANSPOSED on both sides, inner > 1,
+ *                TFFT_SCALE_ONCE (the plan's last fp32 multiply lies in front of its last stage) and every variant bit
+ *                but the column-pass bits 262144 / 524288. The reference has neither order (nor an inverse):
+ *                src/base/TensorFFT256.cu:163-177 only comments on scaling. */
 enum { TFFT_ORDER_NATURAL = 0, TFFT_ORDER_TRANSPOSED = 1 };
 
 /* Host only. N2 of the TRANSPOSED order for length n (0: no two-pass split, natural order is produced). */

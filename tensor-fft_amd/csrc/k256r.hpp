@@ -247,8 +247,13 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
         stockham::dft<R>(v);
         if (OTW) {                     // transposed-input plan: output kk + 256 s of row (b0 + t) & row_mask times w_N^(row (kk + 256 s))
           const uint32_t row = (b0 + static_cast<uint32_t>(t)) & otw.row_mask;
+          const Cf step = otw_w(otw, row, 256);
+          Cf tw = otw_w(otw, row, 4u * g + reg + 16u * x);
 #pragma unroll
-          for (int s = 0; s < R; ++s) otw_apply(otw, row, 4u * g + reg + 16u * x + 256u * s, v[s].re, v[s].im);
+          for (int s = 0; s < R; ++s) {
+            cmul_to(v[s].re, v[s].im, tw);
+            if (s + 1 < R) cmul_to(tw.re, tw.im, step);
+          }
         }
 #pragma unroll
         for (int s = 0; s < R; ++s) {

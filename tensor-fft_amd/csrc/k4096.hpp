@@ -105,12 +105,21 @@ struct OutTw {
   uint32_t n_mask = 0, row_mask = 0;
   float inv_n = 0.f;
 };
-__device__ __forceinline__ void otw_apply(const OutTw& t, uint32_t row, uint32_t q, float& re, float& im) {
+struct Cf {
+  float re, im;
+};
+// w_N^(row q)
+__device__ __forceinline__ Cf otw_w(const OutTw& t, uint32_t row, uint32_t q) {
   const float a = static_cast<float>((row * q) & t.n_mask) * t.inv_n;
-  const float c = __builtin_amdgcn_cosf(a), s = -__builtin_amdgcn_sinf(a);
-  const float r = __builtin_fmaf(re, c, -(im * s));
-  im = __builtin_fmaf(re, s, im * c);
+  return Cf{__builtin_amdgcn_cosf(a), -__builtin_amdgcn_sinf(a)};
+}
+__device__ __forceinline__ void cmul_to(float& re, float& im, const Cf w) {
+  const float r = __builtin_fmaf(re, w.re, -(im * w.im));
+  im = __builtin_fmaf(re, w.im, im * w.re);
   re = r;
+}
+__device__ __forceinline__ void otw_apply(const OutTw& t, uint32_t row, uint32_t q, float& re, float& im) {
+  cmul_to(re, im, otw_w(t, row, q));
 }
 
 // ---------------------------------------------------------------------------
@@ -465,6 +474,13 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
 
     uint16_t* const fft_re = out_re + out_map.off(b);
     uint16_t* const fft_im = out_im + out_map.off(b);
+    Cf otw_t[4], otw_s;
+    if (OTW) {
+      const uint32_t row = b & otw.row_mask;
+      otw_s = otw_w(otw, row, 1);
+#pragma unroll
+      for (int r2 = 0; r2 < 4; ++r2) otw_t[r2] = otw_w(otw, row, 16u * (lane & 15) + 256u * (4 * g + r2));
+    }
 
     // ---- stages 2 and 3, tile by tile; 8 tiles fill one 16-byte output vector
     auto tile23 = [&](int k0, f4& o_re, f4& o_im) {
@@ -490,13 +506,15 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       o_re = mfma(__builtin_bit_cast(h8, hraw), bop);   // o[r2] = X[k0 + 16 k1 + 256 (4g + r2)]
       o_im = mfma(im_form(hraw), bop);
       if (OTW) {
-        const uint32_t row = b & otw.row_mask;
+        // output k0 + 16 k1 + 256 (4g + r2) of row `b & row_mask` times w_N^(row k): otw_t[r2] holds the twiddle of the CURRENT
+        // tile (the tiles run k0 = 0, 1, ..., 15 in order) and steps by w_N^row: 10 v_sin / v_cos per transform instead of 128
 #pragma unroll
         for (int r2 = 0; r2 < 4; ++r2) {
           float vr = o_re[r2], vi = o_im[r2];
-          otw_apply(otw, row, k0 + 16u * (lane & 15) + 256u * (4 * g + r2), vr, vi);
+          cmul_to(vr, vi, otw_t[r2]);
           o_re[r2] = vr;
           o_im[r2] = vi;
+          cmul_to(otw_t[r2].re, otw_t[r2].im, otw_s);
         }
       }
     };

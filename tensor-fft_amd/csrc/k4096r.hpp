@@ -272,6 +272,13 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         transpose4(pi[0 + pp][r], pi[2 + pp][r], pi[4 + pp][r], pi[6 + pp][r]);
       }
 
+    Cf otw_t[4], otw_s;
+    if (OTW) {
+      const uint32_t row = b & otw.row_mask;
+      otw_s = otw_w(otw, row, R);
+#pragma unroll
+      for (int r2 = 0; r2 < 4; ++r2) otw_t[r2] = otw_w(otw, row, static_cast<uint32_t>(R) * (16u * (lane & 15) + 256u * (4 * g + r2)) + s);
+    }
     // ---- stages 2 and 3 tile by tile; the spectrum of u_s is staged in this wave's region in natural order
     auto tile23 = [&](int k0, f4& o_re, f4& o_im) {
       const int a = k0 >> 2, r = k0 & 3;
@@ -291,14 +298,16 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       const u4 hraw = *reinterpret_cast<const u4*>(h_tab + k0 * 1024);
       o_re = mfma(__builtin_bit_cast(h8, hraw), bop);   // o[r2] = U_s[k0 + 16 k1 + 256 (4g + r2)]
       o_im = mfma(im_form(hraw), bop);
-      if (OTW) {                       // transposed-input plan: output R kk + s of row b & row_mask times w_N^(row (R kk + s))
-        const uint32_t row = b & otw.row_mask;
+      if (OTW) {
+        // transposed-input plan: output R kk + s (kk = k0 + 16 k1 + 256 (4g + r2)) of row b & row_mask times w_N^(row (R kk + s));
+        // otw_t[r2] is the twiddle of the current tile (k0 = 0 .. 15 in order) and steps by w_N^(row R)
 #pragma unroll
         for (int r2 = 0; r2 < 4; ++r2) {
           float vr = o_re[r2], vi = o_im[r2];
-          otw_apply(otw, row, static_cast<uint32_t>(R) * (k0 + 16u * (lane & 15) + 256u * (4 * g + r2)) + s, vr, vi);
+          cmul_to(vr, vi, otw_t[r2]);
           o_re[r2] = vr;
           o_im[r2] = vi;
+          cmul_to(otw_t[r2].re, otw_t[r2].im, otw_s);
         }
       }
     };

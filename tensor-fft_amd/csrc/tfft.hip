@@ -334,6 +334,27 @@ inline uint32_t pick_grid(uint64_t blocks_needed, int num_cus, uint32_t iters) {
   return static_cast<uint32_t>(std::max<uint64_t>(lo, (blocks_needed + iters - 1) / std::max(iters, 1u)));
 }
 
+// Grid of the kernels that used to run as persistent workgroups (column passes, k4096r, the fused 2D row pass). Round 4: a
+// static partition (one workgroup per CU for the whole batch) ends when the SLOWEST CU ends, and on some boxes CUs differ by
+// several per cent; `gens` generations of workgroups, handed out by the hardware dispatcher as CUs drain, balance
+// that dynamically. What it buys depends on the box (three boxes, profiles/r4_iters_scan.txt, r4_gens_scan.txt): 2^16 x 16384
+// (4-wave radix-256 workgroups, 8 generations) +2.6 %, +2.6 %, +6.5 %; the 8-wave radix-256 / 512 / 1024 kernels with 2 generations
+// 0 ... +0.5 % on two boxes and +3.6 ... +5 % on the third (2^20 x 1024: 329 -> 341 Gsamples/s); more generations lose again (tables
+// and pipeline fill are paid per workgroup: 2^20 at 8 generations -3 %). The fused 2D row pass and the 8192 ... 32768 kernels
+// (one iteration = 13 us) keep the static partition (-1 ... -3 % with two generations). Whole multiples of the resident capacity
+// only (a grid of 2.7 capacities leaves a third of the chip idle in its last round: 301 Gsamples/s), and only while every
+// workgroup still gets kMinRounds rounds. tfft_plan_opts.launch_iters overrides (the tuner's knob; TFFT_LAUNCH_PERSISTENT = the
+// static partition).
+inline uint32_t gens_grid(uint64_t blocks, uint32_t capacity, uint32_t launch_iters, uint32_t gens_dflt) {
+  if (launch_iters) return pick_grid(blocks, static_cast<int>(capacity), plan_iters(launch_iters, 1000000u));
+  static const uint32_t gens_env = env_iters("TFFT_GENS", 0);            // experiment knob (debug build only)
+  const uint32_t gens = gens_env ? gens_env : gens_dflt;
+  constexpr uint64_t kMinRounds = 8;
+  if (gens > 1 && blocks >= static_cast<uint64_t>(capacity) * gens * kMinRounds) return capacity * gens;
+  return static_cast<uint32_t>(std::min<uint64_t>(blocks, capacity));
+}
+constexpr uint32_t kGensStatic = 1, kGensCol8 = 2, kGensCol4 = 8;    // per kernel family, see above
+
 template <int V>
 int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                    k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
@@ -427,8 +448,7 @@ int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, vo
   const uint32_t blocks_needed = static_cast<uint32_t>((p->batch + per_wg - 1) / per_wg);
   // persistent workgroups: with four workgroup barriers per transform the short-lived launch shape of the 4096
   // kernel does not help here (measured at 2^13: 405 / 425 / 440 / 457 Gsamples/s for 1 / 2 / 4 / all iterations)
-  static const uint32_t iters_dflt = env_iters("TFFT_K4096R_ITERS", 1000000);   // experiment knob (debug build only)
-  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
+  const uint32_t grid = gens_grid(blocks_needed, static_cast<uint32_t>(p->num_cus), p->launch_iters, kGensStatic);
 #ifdef TFFT_DEBUG_KERNELS
 #define TFFT_NO_STAMPS , static_cast<unsigned long long*>(nullptr)
 #else
@@ -460,7 +480,7 @@ int launch_k4096r(const tfft_plan* p, int radix, const void* in_re, const void* 
 // first pass of the fused 2D plan: iterations = images * 512 (k4096r.hpp, ROWS); p only lends its device and tables
 int launch_rows2d(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                   uint64_t image_stride, uint32_t iterations, hipStream_t s) {
-  const uint32_t grid = std::min<uint32_t>(iterations, static_cast<uint32_t>(p->num_cus));
+  const uint32_t grid = gens_grid(iterations, static_cast<uint32_t>(p->num_cus), 0, kGensStatic);
 #ifdef TFFT_DEBUG_KERNELS
   unsigned long long* stamps = nullptr;      // measurement hook of tools/exp_rows_phases.py
   if (debug_variants_enabled())
@@ -514,7 +534,18 @@ int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   using G = colfft::WgGeom<W>;
   const uint64_t blocks = (a.tasks / a.groups) * a.pitch / G::kCols;
   static const uint32_t iters_dflt = env_iters("TFFT_COLWG_ITERS", 1000000);
-  const uint32_t grid = pick_grid(blocks, p->num_cus * (8 / W), plan_iters(p->launch_iters, iters_dflt));
+#ifdef TFFT_DEBUG_KERNELS
+  // experiment knob: TFFT_WG4_ONE_PER_CU=1 launches the 4-wave workgroups with so much dynamic LDS (96 KiB) that only ONE fits a CU:
+  // the same kernel at one wave per SIMD instead of two (what a radix-1024 pass with 128-column tiles would have to run at)
+  static const bool one_per_cu = W == 4 && env_iters("TFFT_WG4_ONE_PER_CU", 0) != 0;
+  if (one_per_cu) {
+    const uint32_t grid1 = pick_grid(blocks, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
+    TFFT_LAUNCH((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid1), dim3(G::kThreadsW), 96 * 1024, s, a);
+    return TFFT_OK;
+  }
+#endif
+  const uint32_t grid = iters_dflt != 1000000u ? pick_grid(blocks, p->num_cus * (8 / W), plan_iters(p->launch_iters, iters_dflt))
+                                               : gens_grid(blocks, static_cast<uint32_t>(p->num_cus * (8 / W)), p->launch_iters, W == 4 ? kGensCol4 : kGensCol8);
   TFFT_LAUNCH((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid), dim3(G::kThreadsW), G::kLds, s, a);
   return TFFT_OK;
 }
@@ -597,7 +628,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   if (radix == 1024) {
     // (plan creation only emits this pass where the geometry fits: pitch, and ns_f unless it is 1, multiples of 64)
     const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
-    const uint32_t grid = pick_grid(blocks, p->num_cus, plan_iters(p->launch_iters, 1000000u));
+    const uint32_t grid = gens_grid(blocks, static_cast<uint32_t>(p->num_cus), p->launch_iters, kGensCol8);
     if (a.ns_f == 1) {
       if (ps.tw_next)
         TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
@@ -617,7 +648,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     // plan creation only emits this pass where the geometry fits (pitch, and ns_f unless it is 1, multiples of 64)
     const bool on_lanes = (a.ns_f == 1);
     const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
-    const uint32_t grid = pick_grid(blocks, p->num_cus, plan_iters(p->launch_iters, 1000000u));
+    const uint32_t grid = gens_grid(blocks, static_cast<uint32_t>(p->num_cus), p->launch_iters, kGensCol8);
     if (on_lanes) {
       if (ps.tw_next)
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
@@ -636,7 +667,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
         // 128-column tiles (256-byte row segments, one 8-wave workgroup per CU) where the geometry allows and variant bit
         // 524288 does not ask for 4-wave workgroups; otherwise 64-column tiles, two 4-wave workgroups per CU
         const bool w8 = !(p->variant & 524288) && a.pitch % 128 == 0 && a.ns_f % 128 == 0;
-        const uint32_t grid2 = pick_grid(w8 ? blocks / 2 : blocks, (w8 ? 1 : 2) * p->num_cus, plan_iters(p->launch_iters, 1000000u));
+        const uint32_t grid2 = gens_grid(w8 ? blocks / 2 : blocks, static_cast<uint32_t>((w8 ? 1 : 2) * p->num_cus), p->launch_iters, kGensCol8);
         const bool sc = ps.scale != 1.0f;          // TFFT_SCALE_ONCE: the single factor in fp32 at the combine
         if (w8 && sc)
           TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, true>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a);
@@ -1203,6 +1234,11 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device_id);
   p->num_cus = (e == hipSuccess) ? prop.multiProcessorCount : 256;
+#ifdef TFFT_DEBUG_KERNELS
+  // experiment knob: TFFT_NUM_CUS=192 sizes every persistent grid for that many CUs (fewer workgroups than the chip has CUs:
+  // does the memory system serve fewer concurrent streams better?)
+  if (const uint32_t forced = env_iters("TFFT_NUM_CUS", 0)) p->num_cus = static_cast<int>(forced);
+#endif
   auto bail = [&](int code) {
     const std::string keep = g_err;
     tfft_plan_destroy(p);

@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("shape")
 ap.add_argument("variants", nargs="+")
 ap.add_argument("--order", default="natural")
+ap.add_argument("--in-order", default="natural")
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--rounds", type=int, default=5)
 args = ap.parse_args()
@@ -109,7 +110,8 @@ for spec in args.variants:
         mod = capi_for(libname)
     t = rest.split(",")
     v, it = int(t[0]), (int(t[1]) if len(t) > 1 else 0)
-    p = mod.TfftPlan(n, b, 0, inner=inner, variant=v, launch_iters=it, preserve_input=True, output_order=args.order)
+    p = mod.TfftPlan(n, b, 0, inner=inner, variant=v, launch_iters=it, preserve_input=True, output_order=args.order,
+                     input_order=args.in_order)
     ws = torch.empty(max(1, p.workspace_bytes // 2), dtype=torch.float16, device="cuda")
     if p.workspace_bytes:
         p.set_workspace(ws)
