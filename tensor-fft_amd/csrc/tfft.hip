@@ -536,10 +536,12 @@ int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   static const uint32_t iters_dflt = env_iters("TFFT_COLWG_ITERS", 1000000);
 #ifdef TFFT_DEBUG_KERNELS
   // experiment knob: TFFT_WG4_ONE_PER_CU=1 launches the 4-wave workgroups with so much dynamic LDS (96 KiB) that only ONE fits a CU:
-  // the same kernel at one wave per SIMD instead of two (what a radix-1024 pass with 128-column tiles would have to run at)
+  // the same kernel at one wave per SIMD instead of two (what a radix-1024 pass with 128-column tiles would have to run at).
+  // Round 4, against the static partition: +3 ... +10 % on one box; against today's default (8 generations of two per CU), as a
+  // variant bit in one process: -3 ... -20 % (profiles/r4_one_wave_per_simd.txt): not a launch shape worth keeping.
   static const bool one_per_cu = W == 4 && env_iters("TFFT_WG4_ONE_PER_CU", 0) != 0;
   if (one_per_cu) {
-    const uint32_t grid1 = pick_grid(blocks, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
+    const uint32_t grid1 = gens_grid(blocks, static_cast<uint32_t>(p->num_cus), p->launch_iters, env_iters("TFFT_GENS", 1));
     TFFT_LAUNCH((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid1), dim3(G::kThreadsW), 96 * 1024, s, a);
     return TFFT_OK;
   }
