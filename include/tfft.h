@@ -248,7 +248,9 @@ int tfft_exec_inverse(const tfft_plan* plan, const void* in_re, const void* in_i
  * in_re / in_im / out_re / out_im each point at batch * rows * cols halves, image after image, row-major.
  * Result = DFT2(x) / (rows * cols). rows, cols: powers of two, cols >= 8.
  * Scratch: tfft_plan2d_workspace_bytes() of device memory (an intermediate image set plus the column plan's own
- * scratch); hand it in with tfft_plan2d_set_workspace() or let the first execution hipMalloc it. */
+ * scratch); hand it in with tfft_plan2d_set_workspace() or let the first execution hipMalloc it. 4096 x 4096 runs as two
+ * fused passes, chunk by chunk of 4 images through ONE 256-MiB intermediate set (both passes of a chunk back to back: the
+ * Infinity Cache still holds part of it), so its workspace does not grow with the batch. Exact in-place execution is allowed. */
 typedef struct tfft_plan2d tfft_plan2d;
 int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_id, tfft_plan2d** out);
 void tfft_plan2d_destroy(tfft_plan2d* plan);

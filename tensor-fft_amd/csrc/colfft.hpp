@@ -26,6 +26,20 @@
 
 #include "k4096.hpp"
 
+// Streaming hint of the column passes' global accesses (every byte is touched once per pass). -DTFFT_COL_NO_NT builds them as
+// plain accesses: the A/B behind the chunked execution experiments of round 4 (does a non-temporal access keep an intermediate
+// out of the Infinity Cache?).
+#if defined(TFFT_COL_NO_NT) || defined(TFFT_COL_PLAIN_LOADS)
+#define TFFT_NT_LOAD(p) (*(p))
+#else
+#define TFFT_NT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+#if defined(TFFT_COL_NO_NT) || defined(TFFT_COL_PLAIN_STORES)
+#define TFFT_NT_STORE(v, p) (*(p) = (v))
+#else
+#define TFFT_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
 namespace colfft {
 
 using namespace k4096;
@@ -92,6 +106,25 @@ struct Args {
 
 // twiddle forms of a column pass: none, the next autosort pass's input twiddles, the four-step twiddle
 enum : int { kTwNone = 0, kTwNext = 1, kTwFourStep = 2 };
+
+// Store policy of a column pass (round 4). A four-step pass (kTwFourStep) writes the INTERMEDIATE of a transposed-order plan, which
+// the contiguous row pass of the same chunk of the batch reads right back (tfft.hip launch_chain runs those plans chunk by
+// chunk): plain stores, so that the lines stay in the 256-MiB Infinity Cache: 2^20 x 1024 in transposed output order 341-348 ->
+// 375 Gsamples/s (profiles/r4_chunked_transposed.txt). Everything else streams out non-temporally: a plan's last pass so that its
+// output does not push intermediates out, and the kTwNext passes of natural-order plans, which run over the whole batch (chunks
+// and plain stores were measured there too: 2^20 x 1024 341 -> 307-326, profiles/r4_chunked_1d.txt: the strided second pass does
+// not profit from the cache the way a contiguous one does). All loads stay non-temporal: the caller's input must not displace
+// the intermediates, and an intermediate is dead once read (plain loads of it: -16 % in the 2D plan, profiles/r4_ab_2d_chunk.txt).
+// -DTFFT_COL_STREAM_ALL = round 3's policy (everything non-temporal), for A/B builds.
+template <int TW, typename V>
+__device__ __forceinline__ void st_pass(V v, V* p) {
+#ifdef TFFT_COL_STREAM_ALL
+  TFFT_NT_STORE(v, p);
+#else
+  if constexpr (TW == kTwFourStep) *p = v;
+  else TFFT_NT_STORE(v, p);
+#endif
+}
 
 struct cpx {
   float re, im;
@@ -509,8 +542,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         const u4 vr = *reinterpret_cast<const u4*>(img + 8192 * wave + 1024 * i + 16 * lane);
         const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 8192 * wave + 1024 * i + 16 * lane);
         const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
-        __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(c_re + o));
-        __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(c_im + o));
+        st_pass<TW>(vr, reinterpret_cast<u4*>(c_re + o));
+        st_pass<TW>(vi, reinterpret_cast<u4*>(c_im + o));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -651,8 +684,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 8192 * wave + 1024 * i + 16 * lane);
         const uint64_t o = (m0 + f) * 256 + 8 * chunk;
         if (NT) {
-          __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(o_re + o));
-          __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(o_im + o));
+          st_pass<TW>(vr, reinterpret_cast<u4*>(o_re + o));
+          st_pass<TW>(vi, reinterpret_cast<u4*>(o_im + o));
         } else {
           *reinterpret_cast<u4*>(o_re + o) = vr;
           *reinterpret_cast<u4*>(o_im + o) = vi;
@@ -679,8 +712,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         }
         const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
         if (NT) {
-          __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(o_re + o));
-          __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(o_im + o));
+          st_pass<TW>(vr, reinterpret_cast<u4*>(o_re + o));
+          st_pass<TW>(vi, reinterpret_cast<u4*>(o_im + o));
         } else {
           *reinterpret_cast<u4*>(o_re + o) = vr;
           *reinterpret_cast<u4*>(o_im + o) = vi;
@@ -769,8 +802,8 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       const uint32_t chunk = v % kCpr;
       const uint32_t row = 2 * r + seq;
       const uint64_t off = (row * a.pitch + static_cast<uint64_t>(row >> a.in_seg_shift) * a.in_seg_gap + mb + 8 * chunk) * 2;
-      raw_re[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off));
-      raw_im[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off));
+      raw_re[i] = TFFT_NT_LOAD(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off));
+      raw_im[i] = TFFT_NT_LOAD(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off));
     }
   };
   Rotor rot(blockIdx.x, gridDim.x);                          // (block order: k4096::Rotor)
@@ -924,10 +957,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
         const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
         const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
         const uint64_t o0 = (mb + f) * 512 + k0;
-        __builtin_nontemporal_store(s0r, reinterpret_cast<u4*>(c_re + o0));
-        __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(c_im + o0));
-        __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(c_re + o0 + 256));
-        __builtin_nontemporal_store(s1i, reinterpret_cast<u4*>(c_im + o0 + 256));
+        st_pass<TW>(s0r, reinterpret_cast<u4*>(c_re + o0));
+        st_pass<TW>(s0i, reinterpret_cast<u4*>(c_im + o0));
+        st_pass<TW>(s1r, reinterpret_cast<u4*>(c_re + o0 + 256));
+        st_pass<TW>(s1i, reinterpret_cast<u4*>(c_im + o0 + 256));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();          // D
@@ -974,10 +1007,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       if (TW == kTwNone && !SC) {
         // last pass: X = A_0 +- A_1 is the output itself: packed binary16 sums (one correct rounding each, exactly what the
         // fp32 path's sum-then-round gives, in 16 instructions instead of 80)
-        __builtin_nontemporal_store(__builtin_bit_cast(u4, ar + br), reinterpret_cast<u4*>(o_re + o0));
-        __builtin_nontemporal_store(__builtin_bit_cast(u4, ai + bi), reinterpret_cast<u4*>(o_im + o0));
-        __builtin_nontemporal_store(__builtin_bit_cast(u4, ar - br), reinterpret_cast<u4*>(o_re + o1));
-        __builtin_nontemporal_store(__builtin_bit_cast(u4, ai - bi), reinterpret_cast<u4*>(o_im + o1));
+        st_pass<TW>(__builtin_bit_cast(u4, ar + br), reinterpret_cast<u4*>(o_re + o0));
+        st_pass<TW>(__builtin_bit_cast(u4, ai + bi), reinterpret_cast<u4*>(o_im + o0));
+        st_pass<TW>(__builtin_bit_cast(u4, ar - br), reinterpret_cast<u4*>(o_re + o1));
+        st_pass<TW>(__builtin_bit_cast(u4, ai - bi), reinterpret_cast<u4*>(o_im + o1));
         continue;
       }
       float x0r[8], x0i[8], x1r[8], x1i[8];
@@ -1042,10 +1075,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       const u4 s0i = {pk(x0i[0], x0i[1]), pk(x0i[2], x0i[3]), pk(x0i[4], x0i[5]), pk(x0i[6], x0i[7])};
       const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
       const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
-      __builtin_nontemporal_store(s0r, reinterpret_cast<u4*>(o_re + o0));
-      __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(o_im + o0));
-      __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(o_re + o1));
-      __builtin_nontemporal_store(s1i, reinterpret_cast<u4*>(o_im + o1));
+      st_pass<TW>(s0r, reinterpret_cast<u4*>(o_re + o0));
+      st_pass<TW>(s0i, reinterpret_cast<u4*>(o_im + o0));
+      st_pass<TW>(s1r, reinterpret_cast<u4*>(o_re + o1));
+      st_pass<TW>(s1i, reinterpret_cast<u4*>(o_im + o1));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // D: read out; the next block's copy-in may overwrite the images

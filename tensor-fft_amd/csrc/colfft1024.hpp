@@ -107,8 +107,8 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint64_t off = row_offset(blk, i, 0, ll);
-      ra_re[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off));
-      ra_im[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off));
+      ra_re[i] = TFFT_NT_LOAD(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_re + bidx * a.in_stride) + off));
+      ra_im[i] = TFFT_NT_LOAD(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off));
     }
   };
   auto dma_round1 = [&](uint32_t blk) {
@@ -354,10 +354,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
           const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
           const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
           const uint64_t o0 = (mb + f) * 1024 + k0;
-          __builtin_nontemporal_store(s0r, reinterpret_cast<u4*>(c_re + o0));
-          __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(c_im + o0));
-          __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(c_re + o0 + 512));
-          __builtin_nontemporal_store(s1i, reinterpret_cast<u4*>(c_im + o0 + 512));
+          st_pass<TW>(s0r, reinterpret_cast<u4*>(c_re + o0));
+          st_pass<TW>(s0i, reinterpret_cast<u4*>(c_im + o0));
+          st_pass<TW>(s1r, reinterpret_cast<u4*>(c_re + o0 + 512));
+          st_pass<TW>(s1i, reinterpret_cast<u4*>(c_im + o0 + 512));
           __builtin_amdgcn_sched_barrier(0);     // one chunk at a time (registers)
         }
         return;
@@ -395,10 +395,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
         if (TW == kTwNone && !SC) {
           // last pass: the combine IS the output: packed binary16 sums (one correct rounding each, what the fp32 path's
           // sum-then-round gives, in 16 instructions instead of 80). -i D = (D.im, -D.re).
-          __builtin_nontemporal_store(__builtin_bit_cast(u4, j ? ar + bi : ar + br), reinterpret_cast<u4*>(o_re + o0));
-          __builtin_nontemporal_store(__builtin_bit_cast(u4, j ? ai - br : ai + bi), reinterpret_cast<u4*>(o_im + o0));
-          __builtin_nontemporal_store(__builtin_bit_cast(u4, j ? ar - bi : ar - br), reinterpret_cast<u4*>(o_re + o1));
-          __builtin_nontemporal_store(__builtin_bit_cast(u4, j ? ai + br : ai - bi), reinterpret_cast<u4*>(o_im + o1));
+          st_pass<TW>(__builtin_bit_cast(u4, j ? ar + bi : ar + br), reinterpret_cast<u4*>(o_re + o0));
+          st_pass<TW>(__builtin_bit_cast(u4, j ? ai - br : ai + bi), reinterpret_cast<u4*>(o_im + o0));
+          st_pass<TW>(__builtin_bit_cast(u4, j ? ar - bi : ar - br), reinterpret_cast<u4*>(o_re + o1));
+          st_pass<TW>(__builtin_bit_cast(u4, j ? ai + br : ai - bi), reinterpret_cast<u4*>(o_im + o1));
           __builtin_amdgcn_sched_barrier(0);
           continue;
         }
@@ -442,10 +442,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
         const u4 s0i = {pk(x0i[0], x0i[1]), pk(x0i[2], x0i[3]), pk(x0i[4], x0i[5]), pk(x0i[6], x0i[7])};
         const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
         const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
-        __builtin_nontemporal_store(s0r, reinterpret_cast<u4*>(o_re + o0));
-        __builtin_nontemporal_store(s0i, reinterpret_cast<u4*>(o_im + o0));
-        __builtin_nontemporal_store(s1r, reinterpret_cast<u4*>(o_re + o1));
-        __builtin_nontemporal_store(s1i, reinterpret_cast<u4*>(o_im + o1));
+        st_pass<TW>(s0r, reinterpret_cast<u4*>(o_re + o0));
+        st_pass<TW>(s0i, reinterpret_cast<u4*>(o_im + o0));
+        st_pass<TW>(s1r, reinterpret_cast<u4*>(o_re + o1));
+        st_pass<TW>(s1i, reinterpret_cast<u4*>(o_im + o1));
         __builtin_amdgcn_sched_barrier(0);
       }
     };

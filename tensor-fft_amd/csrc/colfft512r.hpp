@@ -180,8 +180,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft512r_wg_kernel(Args a) {
       const uint32_t v = (lane & 15) ^ (2 * (((sr * kRps) >> 4) & 7));
       const uint32_t row = 2 * (sr * kRps + v / kCpr);
       const uint64_t off = (row * a.pitch + static_cast<uint64_t>(row >> a.in_seg_shift) * a.in_seg_gap + 8 * (v % kCpr)) * 2;
-      ra_re[PF ? i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(b_re) + off));
-      ra_im[PF ? i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(b_im) + off));
+      ra_re[PF ? i : 0] = TFFT_NT_LOAD(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(b_re) + off));
+      ra_im[PF ? i : 0] = TFFT_NT_LOAD(reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(b_im) + off));
     }
   };
   auto to_image = [&]() {
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft512r_wg_kernel(Args a) {
           vi = u4{vi.z, vi.w, vi.x, vi.y};
         }
         const uint64_t o = obase + (static_cast<uint64_t>(k + krow0) << row_shift) + 8 * chunk;
-        __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(o_re + o));
-        __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(o_im + o));
+        TFFT_NT_STORE(vr, reinterpret_cast<u4*>(o_re + o));
+        TFFT_NT_STORE(vi, reinterpret_cast<u4*>(o_im + o));
       }
     };
     read_out(0);

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
       const u4 v = *reinterpret_cast<const u4*>(wl + t * 1024 + 16 * lane);
       if (static_cast<uint32_t>(t) < nb) {
         uint16_t* dst = ((lane < 32) ? out_re : out_im) + out_map.off(b0 + t) + 8 * (lane & 31);
-        __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
+        if (OTW) *reinterpret_cast<u4*>(dst) = v;      // intermediate of a transposed-input plan: stays in the Infinity Cache for the column pass
+        else __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image consumed before the next copy-in lands on it

@@ -292,7 +292,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
         const u4 v = *reinterpret_cast<const u4*>(wl + i * 1024 + 16 * lane);
         if (static_cast<uint32_t>(t) < nb) {
           uint16_t* dst = (plane ? out_im : out_re) + out_map.off(b0 + t) + 512 * pq + 8 * lane;
-          __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
+          if (OTW) *reinterpret_cast<u4*>(dst) = v;      // intermediate of a transposed-input plan (see k256.hpp)
+          else __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
         }
       }
     }

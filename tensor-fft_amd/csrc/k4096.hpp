@@ -334,9 +334,11 @@ __device__ __forceinline__ void dma_in(const uint8_t* src_re, const uint8_t* src
   }
 }
 
-template <int V>
+// (KEEP: the row pass of a transposed-input plan writes an intermediate that the column pass of the same chunk reads right
+// back: plain stores, so that it stays in the Infinity Cache)
+template <int V, bool KEEP = false>
 __device__ __forceinline__ void st(uint16_t* p, u4 v) {
-  if (V & kNonTemporal)
+  if ((V & kNonTemporal) && !KEEP)
     __builtin_nontemporal_store(v, reinterpret_cast<u4*>(p));
   else
     *reinterpret_cast<u4*>(p) = v;
@@ -419,8 +421,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
                reinterpret_cast<const uint8_t*>(in_im + in_map.off(nb0)), wl_off, lane);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        st<V>(f_re + 512 * i + 8 * lane, vr[i]);
-        st<V>(f_im + 512 * i + 8 * lane, vi[i]);
+        st<V, OTW>(f_re + 512 * i + 8 * lane, vr[i]);
+        st<V, OTW>(f_im + 512 * i + 8 * lane, vi[i]);
       }
       if (nb0 >= batch) break;
       b = nb0;
@@ -537,8 +539,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
         const u4 vr = {ore[r2][0], ore[r2][1], ore[r2][2], ore[r2][3]};
         const u4 vi = {oim[r2][0], oim[r2][1], oim[r2][2], oim[r2][3]};
         if (V & kFakeStore) {
-          st<V>(fft_re + 8 * lane + 512 * (2 * r2 + half), vr);
-          st<V>(fft_im + 8 * lane + 512 * (2 * r2 + half), vi);
+          st<V, OTW>(fft_re + 8 * lane + 512 * (2 * r2 + half), vr);
+          st<V, OTW>(fft_im + 8 * lane + 512 * (2 * r2 + half), vi);
         } else if (V & kStageOut) {
           // byte offset of this piece in the [RE 8 KiB | IM 8 KiB] image: 32 k1 + 16 half + 512 (4g + r2);
           // the 16-byte slot index (2 k1 + half) is XORed with bit 3 of itself so that lanes k1 and
@@ -548,8 +550,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
           *reinterpret_cast<u4*>(wl + off) = vr;
           *reinterpret_cast<u4*>(wl + 8192 + off) = vi;
         } else {
-          st<V>(fft_re + out_lane_off + 256 * r2 + 8 * half, vr);
-          st<V>(fft_im + out_lane_off + 256 * r2 + 8 * half, vi);
+          st<V, OTW>(fft_re + out_lane_off + 256 * r2 + 8 * half, vr);
+          st<V, OTW>(fft_im + out_lane_off + 256 * r2 + 8 * half, vi);
         }
       }
     }
@@ -560,8 +562,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
       for (int i = 0; i < 8; ++i) {
         const u4 vr = *reinterpret_cast<const u4*>(wl + 1024 * i + rd);
         const u4 vi = *reinterpret_cast<const u4*>(wl + 8192 + 1024 * i + rd);
-        st<V>(fft_re + 512 * i + 8 * lane, vr);
-        st<V>(fft_im + 512 * i + 8 * lane, vi);
+        st<V, OTW>(fft_re + 512 * i + 8 * lane, vr);
+        st<V, OTW>(fft_im + 512 * i + 8 * lane, vi);
       }
     }
     if (nb >= batch) break;

@@ -136,14 +136,13 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       const int rho = 4 * fg + jj;
       const int h = rho / (2 * R), pl = (rho % (2 * R)) / R, i = rho % R;
       const uint16_t* const src = (pl ? in_im : in_re) + base + kBlockStep * i + 8u * (64u * (s * kPs + h) + fn);
-      // (2D rows: plain accesses, here and at the stores below: measured 3.65-3.75 -> 3.47 ms for 4096^2 x 64; the batched 1D
-      // transforms are the other way round: 738 -> 726 Gsamples/s without the non-temporal hint. Round 3, in one process:
-      // non-temporal loads alone 3.54 -> 3.73 ms, stores alone 3.53, both 3.48 +- 0.1: nothing to gain either way. A plain copy
-      // with this pass's access pattern, 8-KiB rows 4 MiB apart in planes 2 GiB apart, reaches 5.3-5.5 TB/s, tools/rows2d_copy.hip,
-      // not the 6.1 TB/s of [RE|IM] blocks; this pass runs at 4.8)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        raw[j][jj] = ROWS ? *reinterpret_cast<const u4*>(src + 128 * j) : __builtin_nontemporal_load(reinterpret_cast<const u4*>(src + 128 * j));
+        // Non-temporal in both forms. The 2D row pass ran with plain loads through round 3 (whole batch per pass: 3.65-3.75 ->
+        // 3.47 ms); since round 4 the fused 2D plan runs chunk by chunk so that the column pass finds the intermediate images in
+        // the Infinity Cache, and then the input stream must not push them out: 4096^2 x 64 with chunks of 4 images 3.57 ms with
+        // plain input loads, 3.06-3.10 ms with non-temporal ones (profiles/r4_ab_2d_chunk.txt)
+        raw[j][jj] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src + 128 * j));
     }
   };
   Rotor rot(blockIdx.x, gridDim.x);                       // (iteration order: k4096::Rotor)
@@ -408,8 +407,13 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         two(rb + 8192, vi);
       }
       if (live) {
-        __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(f_out_re + 512 * i + 8 * lane));
-        __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(f_out_im + 512 * i + 8 * lane));
+        if (OTW) {       // intermediate of a transposed-input plan: plain stores, it stays in the Infinity Cache for the column pass
+          *reinterpret_cast<u4*>(f_out_re + 512 * i + 8 * lane) = vr;
+          *reinterpret_cast<u4*>(f_out_im + 512 * i + 8 * lane) = vi;
+        } else {
+          __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(f_out_re + 512 * i + 8 * lane));
+          __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(f_out_im + 512 * i + 8 * lane));
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

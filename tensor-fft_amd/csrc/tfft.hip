@@ -160,6 +160,13 @@ struct tfft_plan {
   tfft_plan* sub_col = nullptr;
   tfft_plan* sub_row = nullptr;
   bool rows_first = false;
+  // Round 4: both sub-plans are built for `chunk` transforms and the batch runs chunk by chunk, both passes of a chunk back to
+  // back through ONE workspace of chunk transforms: the contiguous pass then finds (or leaves) the intermediate in the 256-MiB
+  // Infinity Cache. 2^20 x 1024, transposed output: 341-348 -> 375 Gsamples/s (profiles/r4_chunked_transposed.txt). *_tail: the
+  // sub-plans of the last, shorter chunk.
+  uint64_t chunk = 0;
+  tfft_plan* sub_col_tail = nullptr;
+  tfft_plan* sub_row_tail = nullptr;
   void* d_tables = nullptr;     // k4096::build_tables blob (K4096 and Col256 passes)
   float2* d_tw_lo = nullptr;    // w_n tables (Col256 and Stockham passes)
   float2* d_tw_hi = nullptr;
@@ -816,17 +823,30 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
       if (rc) return rc;
       w = static_cast<_Float16*>(p->ws);
     }
-    _Float16* const w_im = w + p->batch * p->n;
-    if (p->rows_first) {
-      // transposed-order INPUT: N1 contiguous N2-point transforms per [N1][N2] block (output twiddle w_N^(k1 q) in their epilogue)
-      // into the workspace, then one radix-N1 column pass over k1 writes X[q + N2 p] in natural order
-      int rc = launch_chain(p->sub_row, in_re, in_im, w, w_im, s);
+    _Float16* const w_im = w + p->chunk * p->n;
+    const _Float16 *i_re = static_cast<const _Float16*>(in_re), *i_im = static_cast<const _Float16*>(in_im);
+    _Float16 *o_re = static_cast<_Float16*>(out_re), *o_im = static_cast<_Float16*>(out_im);
+    for (uint64_t b0 = 0; b0 < p->batch; b0 += p->chunk) {
+      const bool tail = p->batch - b0 < p->chunk;
+      const tfft_plan* const col = tail ? p->sub_col_tail : p->sub_col;
+      const tfft_plan* const row = tail ? p->sub_row_tail : p->sub_row;
+      const uint64_t io = b0 * p->in_stride, oo = b0 * p->out_stride;
+      int rc;
+      if (p->rows_first) {
+        // transposed-order INPUT: N1 contiguous N2-point transforms per [N1][N2] block (output twiddle w_N^(k1 q) in their
+        // epilogue) into the workspace, then one radix-N1 column pass over k1 writes X[q + N2 p] in natural order
+        rc = launch_chain(row, i_re + io, i_im + io, w, w_im, s);
+        if (rc) return rc;
+        rc = launch_chain(col, w, w_im, o_re + oo, o_im + oo, s);
+      } else {
+        rc = launch_chain(col, i_re + io, i_im + io, w, w_im, s);
+        if (rc) return rc;
+        rc = launch_chain(row, w, w_im, o_re + oo, o_im + oo, s);
+      }
       if (rc) return rc;
-      return launch_chain(p->sub_col, w, w_im, out_re, out_im, s);
+      if (g_prepare && !p->sub_col_tail) break;      // (prepare mode: one walk per distinct sub-plan is enough)
     }
-    int rc = launch_chain(p->sub_col, in_re, in_im, w, w_im, s);
-    if (rc) return rc;
-    return launch_chain(p->sub_row, w, w_im, out_re, out_im, s);
+    return TFFT_OK;
   }
   int np = static_cast<int>(p->passes.size());
   if (kDebugBuild && ((p->variant >> 8) & 15)) np = std::min(np, (p->variant >> 8) & 15);   // debugging aid: run only the first passes
@@ -1056,6 +1076,14 @@ int apply_scale_mode(tfft_plan* p, const InternalOpts& io, k4096::TableScale& ts
 
 int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts, const InternalOpts& io, tfft_plan** out);
 
+// Transforms per chunk of a transposed-order plan: about 512 MiB of intermediate (measured, profiles/r4_chunked_transposed.txt:
+// 2^20 x 1024 in chunks of 256 / 128 / 64 / 32 transforms 368 / 375 / 374 / 349 Gsamples/s against 348 for the whole batch; 2^24 x
+// 64 in chunks of 16 / 8 / 4: 322 / 319 / 309 against 311), never chunks so short that a launch has less than 2^26 samples
+inline uint64_t transposed_chunk(uint64_t n, uint64_t batch) {
+  const uint64_t per = std::max<uint64_t>(1, (uint64_t{1} << 27) / n);       // 2^27 samples x 4 B = 512 MiB
+  return std::min<uint64_t>(batch, per);
+}
+
 int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   // N = N1 N2: column pass (n = N1 along the strided axis, N2 columns, four-step twiddle w_N^(k1 n2)) into the planar
   // workspace [RE: batch x N | IM: batch x N], then batch * N1 contiguous N2-point transforms from it into `out`, where
@@ -1078,7 +1106,10 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   co.scale = mode == TFFT_SCALE_SEQUENTIAL ? TFFT_SCALE_SEQUENTIAL : TFFT_SCALE_NONE;
   co.fourstep_n = n;
   co.launch_iters = p->launch_iters;
-  int rc = create_plan(n1, p->batch, device_id, &co, InternalOpts{}, &p->sub_col);
+  p->chunk = transposed_chunk(n, p->batch);
+  const uint64_t tail = p->batch % p->chunk;
+  int rc = create_plan(n1, p->chunk, device_id, &co, InternalOpts{}, &p->sub_col);
+  if (rc == TFFT_OK && tail) rc = create_plan(n1, tail, device_id, &co, InternalOpts{}, &p->sub_col_tail);
   if (rc) return rc;
   tfft_plan_opts ro = TFFT_PLAN_OPTS_INIT;
   ro.in_batch_stride = n2;
@@ -1092,7 +1123,9 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   ri.in_gstride = n;                       // planar workspace: row b at b * N2 either way
   ri.out_gstride = p->out_stride;
   ri.once_log2 = ilog2(n);
-  return create_plan(n2, p->batch * n1, device_id, &ro, ri, &p->sub_row);
+  rc = create_plan(n2, p->chunk * n1, device_id, &ro, ri, &p->sub_row);
+  if (rc == TFFT_OK && tail) rc = create_plan(n2, tail * n1, device_id, &ro, ri, &p->sub_row_tail);
+  return rc;
 }
 
 // tfft_plan_opts as the caller holds it -> the library's own (current) layout: exactly struct_size bytes are read, every
@@ -1146,7 +1179,10 @@ int create_transposed_in(tfft_plan* p, int device_id) {
   ri.in_gstride = p->in_stride;            // the rows of one transform sit N2 apart inside the caller's [RE | IM] block
   ri.out_gstride = n;                      // planar workspace: row b at b * N2 either way
   ri.otw_n = n;
-  int rc = create_plan(n2, p->batch * n1, device_id, &ro, ri, &p->sub_row);
+  p->chunk = transposed_chunk(n, p->batch);
+  const uint64_t tail = p->batch % p->chunk;
+  int rc = create_plan(n2, p->chunk * n1, device_id, &ro, ri, &p->sub_row);
+  if (rc == TFFT_OK && tail) rc = create_plan(n2, tail * n1, device_id, &ro, ri, &p->sub_row_tail);
   if (rc) return rc;
   tfft_plan_opts co = TFFT_PLAN_OPTS_INIT;
   co.in_batch_stride = n;
@@ -1156,7 +1192,8 @@ int create_transposed_in(tfft_plan* p, int device_id) {
   co.scale = p->scale_mode;
   co.launch_iters = p->launch_iters;
   co.variant = (p->variant & kColBits) | (n1 == 512 ? 67108864 : 0);
-  rc = create_plan(n1, p->batch, device_id, &co, InternalOpts{}, &p->sub_col);
+  rc = create_plan(n1, p->chunk, device_id, &co, InternalOpts{}, &p->sub_col);
+  if (rc == TFFT_OK && tail) rc = create_plan(n1, tail, device_id, &co, InternalOpts{}, &p->sub_col_tail);
   if (rc) return rc;
   if (p->sub_col->passes.size() != 1 || p->sub_col->passes[0].kind != PassKind::Col256)
     return fail(TFFT_ERR_ARG, "transposed-order input: the column transform of this length does not plan as one pass");
@@ -1385,6 +1422,8 @@ void tfft_plan_destroy(tfft_plan* p) {
   if (!p) return;
   tfft_plan_destroy(p->sub_col);
   tfft_plan_destroy(p->sub_row);
+  tfft_plan_destroy(p->sub_col_tail);
+  tfft_plan_destroy(p->sub_row_tail);
   if (p->d_tables) (void)hipFree(p->d_tables);
   if (p->d_tw_lo) (void)hipFree(p->d_tw_lo);
   if (p->d_tw_hi) (void)hipFree(p->d_tw_hi);
@@ -1424,7 +1463,7 @@ int tfft_plan_num_launches(const tfft_plan* p) {
 }
 
 size_t tfft_plan_workspace_bytes(const tfft_plan* p) {
-  if (p && p->sub_col) return static_cast<size_t>(p->batch) * p->n * 4;   // planar intermediate [RE | IM]
+  if (p && p->sub_col) return static_cast<size_t>(p->chunk) * p->n * 4;   // planar intermediate [RE | IM] of ONE chunk of the batch
   if (!p || p->passes.size() == 1) {
     // a single pass needs scratch only when asked to run in place
     if (!p || single_kernel(p)) return 0;
@@ -1499,6 +1538,14 @@ struct tfft_plan2d {
   uint64_t rows = 0, cols = 0, batch = 0;
   int device = 0;
   bool fused = false;       // 4096 x 4096: radix-8 column butterfly fused into the row pass + one radix-512 column pass
+  // Fused plan, round 4: the batch runs in chunks of `chunk` images, both passes of a chunk back to back, through ONE
+  // intermediate image set of chunk images that every chunk re-uses. The 256-MiB Infinity Cache then still holds part of what the
+  // row pass wrote when the column pass reads it: 4096^2 x 64 3.45-3.50 -> 3.33 ms (+3.5 ... +5 %, profiles/r4_2d_chunked.txt;
+  // 4 images = 256 MiB of intermediate is the measured optimum: 2 images pay more for the ramp and tail of their 50-us launches
+  // than the cache returns, 8 images no longer fit), and the workspace is 256 MiB instead of 4 GiB. col_tail: the column plan
+  // of the last, shorter chunk.
+  uint64_t chunk = 0;
+  tfft_plan* col_tail = nullptr;
   mutable std::mutex ws_mutex;
   mutable void* ws = nullptr;
   mutable size_t ws_bytes = 0;
@@ -1536,7 +1583,21 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
       co.out_batch_stride = rows * cols;
       co.inner = cols;
       co.variant = 67108864;
-      rc = tfft_plan_create(512, batch * 8, device_id, &co, &p->col);
+#ifdef TFFT_2D_CHUNK           // A/B knob
+      constexpr uint64_t kChunkImages = TFFT_2D_CHUNK;
+#else
+      constexpr uint64_t kChunkImages = 4;
+#endif
+      p->chunk = std::min<uint64_t>(batch, kChunkImages);
+      rc = tfft_plan_create(512, p->chunk * 8, device_id, &co, &p->col);
+      if (rc == TFFT_OK && batch % p->chunk) {
+        rc = tfft_plan_create(512, (batch % p->chunk) * 8, device_id, &co, &p->col_tail);
+        if (rc == TFFT_OK) {
+          p->col_tail->out_row_shift = 3;
+          p->col_tail->out_sub_shift = 3;
+          p->col_tail->out_sub_stride = cols;
+        }
+      }
       if (rc == TFFT_OK) {
         p->col->out_row_shift = 3;
         p->col->out_sub_shift = 3;
@@ -1579,17 +1640,19 @@ void tfft_plan2d_destroy(tfft_plan2d* p) {
   if (!p) return;
   tfft_plan_destroy(p->row);
   tfft_plan_destroy(p->col);
+  tfft_plan_destroy(p->col_tail);
   if (p->ws && p->ws_owned) (void)hipFree(p->ws);
   delete p;
 }
 
 int tfft_plan2d_num_launches(const tfft_plan2d* p) {
   if (!p) return 0;
+  // (passes over the data; the fused plan issues them chunk by chunk, 2 launches per chunk of images)
   return (p->fused ? 1 : tfft_plan_num_launches(p->row)) + tfft_plan_num_launches(p->col);
 }
 
 namespace {
-inline size_t plan2d_tmp_bytes(const tfft_plan2d* p) { return static_cast<size_t>(p->batch) * p->rows * p->cols * 4; }
+inline size_t plan2d_tmp_bytes(const tfft_plan2d* p) { return static_cast<size_t>(p->fused ? p->chunk : p->batch) * p->rows * p->cols * 4; }
 inline size_t plan2d_part(size_t bytes) { return (bytes + 255) & ~static_cast<size_t>(255); }
 }  // namespace
 
@@ -1643,7 +1706,7 @@ int tfft_plan2d_exec(const tfft_plan2d* p, const void* in_re, const void* in_im,
     }
   }
   _Float16* t_re = static_cast<_Float16*>(p->ws);
-  _Float16* t_im = t_re + static_cast<size_t>(p->batch) * p->rows * p->cols;
+  _Float16* t_im = t_re + static_cast<size_t>(p->fused ? p->chunk : p->batch) * p->rows * p->cols;
   if (p->fused) {
     if (!in_re || !in_im || !out_re || !out_im) return fail(TFFT_ERR_ARG, "null data pointer");
     if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im) | reinterpret_cast<uintptr_t>(out_re) |
@@ -1652,10 +1715,17 @@ int tfft_plan2d_exec(const tfft_plan2d* p, const void* in_re, const void* in_im,
     int cur = 0;
     TFFT_HIP(hipGetDevice(&cur));
     if (cur != p->device) return fail(TFFT_ERR_ARG, "plan was created for another device than the current one");
-    const int rc = launch_rows2d(p->row, in_re, in_im, t_re, t_im, p->rows * p->cols, static_cast<uint32_t>(p->batch * 512),
-                                 static_cast<hipStream_t>(stream));
-    if (rc != TFFT_OK) return rc;
-    return tfft_exec(p->col, t_re, t_im, out_re, out_im, stream);
+    const uint64_t image = p->rows * p->cols;
+    for (uint64_t i = 0; i < p->batch; i += p->chunk) {
+      const uint64_t c = std::min<uint64_t>(p->chunk, p->batch - i);
+      int rc = launch_rows2d(p->row, static_cast<const _Float16*>(in_re) + i * image, static_cast<const _Float16*>(in_im) + i * image, t_re, t_im,
+                             image, static_cast<uint32_t>(c * 512), static_cast<hipStream_t>(stream));
+      if (rc != TFFT_OK) return rc;
+      rc = tfft_exec(c == p->chunk ? p->col : p->col_tail, t_re, t_im, static_cast<_Float16*>(out_re) + i * image,
+                     static_cast<_Float16*>(out_im) + i * image, stream);
+      if (rc != TFFT_OK) return rc;
+    }
+    return TFFT_OK;
   }
   int rc = tfft_exec(p->row, in_re, in_im, t_re, t_im, stream);
   if (rc != TFFT_OK) return rc;

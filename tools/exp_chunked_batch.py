@@ -1,6 +1,7 @@
 """Does running a long-transform batch in cache-sized sub-batches (all passes of one sub-batch back to back) beat one
 plan over the whole batch? The 256-MiB Infinity Cache could keep a sub-batch's intermediate between passes.
-usage: [TFFT_VARIANT=262144] python tools/exp_chunked_batch.py N batch chunk [chunk ...]   (262144 = no non-temporal accesses)"""
+usage: [TFFT_VARIANT=262144] [ORDER=transposed | IN_ORDER=transposed] [TFFT_AB_LIB=build/libtfft_X.so] python tools/exp_chunked_batch.py N batch chunk [chunk ...]
+(262144 = no non-temporal accesses in the radix-256 column kernels)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +11,7 @@ g.build()
 import tensor_fft_amd as tf
 if os.environ.get("TFFT_AB_LIB"):            # another build of the library (file name under tensor-fft_amd/)
     from tensor_fft_amd import capi
-    capi._LIB_NAME = os.environ["TFFT_AB_LIB"]
+    capi._LIB_NAME = os.path.abspath(os.environ["TFFT_AB_LIB"])
     capi._lib = None                            # (g.build() above has already loaded the default build)
 n, batch = int(sys.argv[1]), int(sys.argv[2])
 chunks = [int(v) for v in sys.argv[3:]]
@@ -23,7 +24,8 @@ def timed(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 for c in [batch] + chunks:
-    plan = tf.TfftPlan(n, c, 0, preserve_input=True, variant=int(os.environ.get("TFFT_VARIANT", "0")))
+    plan = tf.TfftPlan(n, c, 0, preserve_input=True, variant=int(os.environ.get("TFFT_VARIANT", "0")),
+                       output_order=os.environ.get("ORDER", "natural"), input_order=os.environ.get("IN_ORDER", "natural"))
     ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
     if plan.workspace_bytes: plan.set_workspace(ws)
     def run():
