@@ -272,3 +272,62 @@ def test_transposed_input_refusals(tf):
         tf.TfftPlan(1 << 20, 4, 0, input_order="transposed", variant=32)
     with pytest.raises(tf.TfftError):
         tf.TfftPlan(1 << 12, 4, 0, inner=64, input_order="transposed")
+
+
+# ---- chunked execution (round 4): the transposed-order plans and the fused 2D plan run the batch chunk by chunk through one
+# chunk-sized workspace; a batch that is not a whole number of chunks ends with a shorter chunk on sub-plans of its own
+@pytest.mark.parametrize("order", ["transposed_out", "transposed_in"])
+def test_chunked_transposed_plans_with_a_tail_chunk(tf, orc, order):
+    import torch
+
+    n = 1 << 16
+    n2 = tf.transposed_n2(n)
+    n1 = n // n2
+    chunk = (1 << 27) // n                       # tfft.hip transposed_chunk: 512 MiB of intermediate
+    batch = chunk + 3
+    x = torch.empty(batch * 2 * n, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x, x[n:], n, batch, seed=77)
+    y = torch.full_like(x, float("nan"))
+    kw = {"output_order": "transposed"} if order == "transposed_out" else {"input_order": "transposed"}
+    plan = tf.TfftPlan(n, batch, 0, preserve_input=True, **kw)
+    assert plan.workspace_bytes == chunk * n * 4                 # ONE chunk of intermediate, whatever the batch
+    plan.exec(x, x[n:], y, y[n:])
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(y).any())
+    for b in (0, chunk - 1, chunk, batch - 1):                   # last of the full chunk, first and last of the tail
+        re, im = orc.synth_uniform(n, 1, b, 77)
+        if order == "transposed_in":                             # the generated block IS the [N1][N2] matrix: x[k1 + N1 k2] = in[k1 N2 + k2]
+            perm = np.arange(n).reshape(n1, n2).T.reshape(-1)
+            re, im = np.ascontiguousarray(re[:, perm]), np.ascontiguousarray(im[:, perm])
+        e_re, e_im = orc.dft64(re, im)
+        exact = e_re[0] + 1j * e_im[0]
+        if order == "transposed_out":
+            exact = exact[np.arange(n).reshape(n2, n1).T.reshape(-1)]     # out[k1 N2 + k2] = X[k1 + N1 k2]
+        o = y[b * 2 * n:(b + 1) * 2 * n].cpu().numpy().astype(np.float64)
+        got = o[:n] + 1j * o[n:]
+        assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL, (order, b)
+
+
+def test_chunked_2d_plan_with_a_tail_chunk_and_in_place(tf, orc):
+    """4096 x 4096 x 6: one chunk of 4 images and a tail of 2; the workspace is one chunk; results equal the batch-1 plan's bit for
+    bit, image by image, also when the plan runs in place."""
+    import torch
+
+    n, images = 4096, 6
+    half = images * n * n
+    x = torch.empty(2 * half, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x[:half], x[half:], n * n, images, batch_stride=n * n, seed=5)
+    y = torch.full_like(x, float("nan"))
+    plan = tf.TfftPlan2D(n, n, images, 0)
+    assert plan.workspace_bytes == 4 * n * n * 4
+    plan.exec(x[:half], x[half:], y[:half], y[half:])
+    one = tf.TfftPlan2D(n, n, 1, 0)
+    z = torch.empty(2 * n * n, dtype=torch.float16, device="cuda")
+    for i in range(images):
+        one.exec(x[i * n * n:(i + 1) * n * n], x[half + i * n * n:half + (i + 1) * n * n], z[:n * n], z[n * n:])
+        torch.cuda.synchronize()
+        assert bool((z[:n * n].view(torch.int16) == y[i * n * n:(i + 1) * n * n].view(torch.int16)).all()), i
+        assert bool((z[n * n:].view(torch.int16) == y[half + i * n * n:half + (i + 1) * n * n].view(torch.int16)).all()), i
+    plan.exec(x[:half], x[half:], x[:half], x[half:])            # in place
+    torch.cuda.synchronize()
+    assert bool((x.view(torch.int16) == y.view(torch.int16)).all())
