@@ -9,7 +9,7 @@ of every kernel's dispatches) from what they fold.
 
     c1      BASELINE configs[1]   4096 x 65536                    (fft4096_kernel)
     c2      BASELINE configs[2]   2^20 x 1024                     (colfft256_wg_kernel x2 + tail)
-    c2t     configs[2] with the transposed-output order (two passes)
+    c2t     configs[2] with the transposed-output order (two passes); c2ti: with the transposed-input order
     c3      BASELINE configs[3]   2D 4096 x 4096 x 64             (fft4096r_kernel<8,true> + colfft512_wg_kernel)
     n8192 / n16384 / n32768       2^28 samples                    (fft4096r_kernel<R>)
     n65536, n262144, n2^26 ...    any "nLEN[:batch]"
@@ -53,6 +53,8 @@ elif name == "c2":
     run1d(1 << 20, 1024)
 elif name == "c2t":
     run1d(1 << 20, 1024, output_order="transposed")
+elif name == "c2ti":
+    run1d(1 << 20, 1024, input_order="transposed")
 elif name == "c3":
     n, b = 4096, 64
     re = ((torch.rand(b * n * n, device="cuda") * 2 - 1)).half()
