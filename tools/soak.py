@@ -1,6 +1,6 @@
 """Randomised soak of the plan space through the C ABI against numpy's fp64 FFT: lengths 2 .. 2^22, batches, padded and
-planar strides, in place, preserve_input, strided axes, scale modes, transposed output order, the four-step twiddle,
-every tuner variant. Each case runs twice (bit-identical results required).
+planar strides, in place, preserve_input, strided axes, scale modes, transposed output and transposed input order (with
+batches that end in a tail chunk of the chunked execution), the four-step twiddle, every tuner variant. Each case runs twice (bit-identical results required).
 
     python tools/soak.py [--seconds 120] [--seed 1]
 
@@ -41,7 +41,7 @@ def main():
     t_last = time.time()
     kinds = {}
     while time.time() < t_end:
-        kind = str(rng.choice(["plain", "plain", "strided", "transposed", "fourstep", "scale", "variant", "launch"]))
+        kind = str(rng.choice(["plain", "plain", "strided", "transposed", "transposed_in", "fourstep", "scale", "variant", "launch"]))
         kw = {}
         inner = 1
         if kind == "strided":
@@ -51,6 +51,10 @@ def main():
             lg = int(rng.integers(16, 23))
             kw["output_order"] = "transposed"
             kw["scale"] = str(rng.choice(["sequential", "sequential", "none", "once"]))
+        elif kind == "transposed_in":               # round 4: the [N1][N2] layout as INPUT, natural order out
+            lg = int(rng.integers(16, 23))
+            kw["input_order"] = "transposed"
+            kw["scale"] = str(rng.choice(["sequential", "sequential", "none"]))
         elif kind == "fourstep":
             lg = int(rng.choice([8, 9]))
             inner = int(rng.choice([64, 128, 512, 2048]))
@@ -74,6 +78,8 @@ def main():
         n = 1 << lg
         nf = n * inner
         batch = int(rng.integers(1, max(2, min(40, (1 << 22) // nf))))
+        if kind in ("transposed", "transposed_in") and lg <= 18 and rng.integers(0, 3) == 0:
+            batch = (1 << 27) // n + int(rng.integers(1, 9))      # one full chunk of the chunked execution plus a tail chunk
         pad = int(rng.integers(0, 3)) * 8 if nf >= 8 and kind in ("plain", "scale", "variant") else 0
         in_place = bool(rng.integers(0, 2)) and pad == 0
         preserve = bool(rng.integers(0, 2)) and not in_place
@@ -82,7 +88,11 @@ def main():
             amp = min(1.0, 8192.0 / n)
         re = (rng.uniform(-1, 1, (batch, n, inner)) * amp).astype(np.float16)
         im = (rng.uniform(-1, 1, (batch, n, inner)) * amp).astype(np.float16)
-        exact = np.fft.fft(_c(re, im), axis=1) / n
+        sig = _c(re, im)
+        if kind == "transposed_in":                 # the block handed over is the [N1][N2] matrix: x[k1 + N1 k2] = in[k1 N2 + k2]
+            n2 = tf.transposed_n2(n)
+            sig = sig.reshape(batch, n // n2, n2).transpose(0, 2, 1).reshape(batch, n, 1)
+        exact = np.fft.fft(sig, axis=1) / n
         if kw.get("scale") == "none":
             exact = exact * n
         if kind == "fourstep":
