@@ -331,3 +331,72 @@ def test_chunked_2d_plan_with_a_tail_chunk_and_in_place(tf, orc):
     plan.exec(x[:half], x[half:], x[:half], x[half:])            # in place
     torch.cuda.synchronize()
     assert bool((x.view(torch.int16) == y.view(torch.int16)).all())
+
+
+def test_dist_set_buffers_validates_ranges_before_it_commits(tf):
+    """tfft_dist_plan_set_buffers used to assign first and check pointer equality only. Now: range overlap over
+    N / world halves, and a refused call leaves the plan on its previous buffers."""
+    import torch
+    from tensor_fft_amd import capi
+
+    n, world = 1 << 20, 2
+    loc = n // world
+    big = torch.zeros(5 * loc, dtype=torch.float16, device="cuda")
+    good = [big[i * loc:(i + 1) * loc] for i in range(4)]
+    p = capi.DistPlan(n, world, 0, 0, buffers=tuple(good))
+    before = [ctypes.c_void_p() for _ in range(4)]
+    capi.load_library().tfft_dist_plan_buffers(p._h, *[ctypes.byref(b) for b in before])
+    assert [b.value for b in before] == [t.data_ptr() for t in good]
+    shifted = big[loc // 2:loc // 2 + loc]                       # overlaps send_re and send_im partially
+    for bad in ((good[0], good[1], shifted, good[3]), (good[0], shifted, good[2], good[3]), (good[0], good[1], good[2], good[2])):
+        with pytest.raises(tf.TfftError) as e:
+            p.set_buffers(*bad)
+        assert e.value.code == 5
+        after = [ctypes.c_void_p() for _ in range(4)]
+        capi.load_library().tfft_dist_plan_buffers(p._h, *[ctypes.byref(b) for b in after])
+        assert [b.value for b in after] == [b.value for b in before]          # nothing changed
+    # a plan created for caller buffers refuses to run before it has them
+    L = capi.load_library()
+    h = ctypes.c_void_p()
+    assert L.tfft_dist_plan_create(n, world, 0, 0, None, capi.DIST_CALLER_BUFFERS, ctypes.byref(h)) == 0
+    assert L.tfft_dist_exec_pre(h, good[0].data_ptr(), good[1].data_ptr(), None) == 5 and "set_buffers" in capi.last_error()
+    L.tfft_dist_plan_destroy(h)
+
+
+def test_transposed_input_is_as_accurate_as_natural_order(tf, orc):
+    """The four-step twiddle of a transposed-input plan is applied to fp32 accumulators (one rounding, like every other stage):
+    its error against the fp64 oracle stays within 10 % of the natural-order plan's on the same signal (and far below the
+    restatement of the reference kernels)."""
+    import torch
+
+    for lg in (16, 20):
+        n = 1 << lg
+        n2 = tf.transposed_n2(n)
+        n1 = n // n2
+        re, im = orc.synth_uniform(n, 1, 0, lg + 100)
+        e_re, e_im = orc.dft64(re, im)
+        exact = e_re[0] + 1j * e_im[0]
+        errs = {}
+        for order in ("natural", "transposed_in"):
+            a, b = re[0], im[0]
+            if order == "transposed_in":
+                a, b = _transposed_layout(a, n1, n2), _transposed_layout(b, n1, n2)
+            x = torch.from_numpy(np.concatenate([a, b])).cuda()
+            y = torch.empty_like(x)
+            tf.TfftPlan(n, 1, 0, preserve_input=True, input_order="transposed" if order == "transposed_in" else "natural").exec(x, x[n:], y, y[n:])
+            torch.cuda.synchronize()
+            o = y.cpu().numpy().astype(np.float64)
+            errs[order] = float(np.linalg.norm(o[:n] + 1j * o[n:] - exact) / np.linalg.norm(exact))
+        assert errs["transposed_in"] <= 1.1 * errs["natural"] + 1e-5, (lg, errs)
+        assert errs["transposed_in"] < 6e-4, (lg, errs)
+
+
+def test_c_abi_spectral_filter_example():
+    """examples/example_spectral_filter.cpp: forward (transposed output, unscaled) -> pointwise delay filter -> inverse (transposed
+    input) through the plain C ABI, 2 + 2 passes; the program checks the delayed signal itself."""
+    exe = os.path.join(ROOT, "examples", "example_spectral_filter")
+    for args in (["22", "8", "5"], ["16", "40", "1"], ["24", "3", "12345"]):
+        r = subprocess.run(["timeout", "-k", "10", "300", exe] + args, capture_output=True, text=True)
+        print(r.stdout, r.stderr)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+        assert "forward 2 passes, inverse 2 passes" in r.stdout
