@@ -1089,7 +1089,7 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   // workspace [RE: batch x N | IM: batch x N], then batch * N1 contiguous N2-point transforms from it into `out`, where
   // the N1 rows of one transform sit N2 apart inside the caller's block (grouped addressing).
   const uint64_t n = p->n, n2 = tfft_plan_transposed_n2(n), n1 = n / n2;
-  if (p->batch * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "batch * N1 too large for one launch");
+  if (transposed_chunk(n, p->batch) * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "chunk * N1 too large for one launch");
   const int mode = p->scale_mode;
   tfft_plan_opts co = TFFT_PLAN_OPTS_INIT;
   co.in_batch_stride = p->in_stride;
@@ -1160,7 +1160,7 @@ int create_transposed_in(tfft_plan* p, int device_id) {
   // their fp32 accumulators) into the planar workspace [RE: batch x N | IM: batch x N]; pass 2: one plain radix-N1 column pass
   // along k1 (N2 columns) from it into `out`, whose row p, column q is X[q + N2 p]: natural order.
   const uint64_t n = p->n, n2 = tfft_plan_transposed_n2(n), n1 = n / n2;
-  if (p->batch * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "batch * N1 too large for one launch");
+  if (transposed_chunk(n, p->batch) * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "chunk * N1 too large for one launch");
   if (p->scale_mode == TFFT_SCALE_ONCE)
     return fail(TFFT_ERR_ARG, "TFFT_SCALE_ONCE is not available with transposed-order input: the plan's last fp32 multiply lies in "
                               "front of its last stage (use TFFT_SCALE_SEQUENTIAL or TFFT_SCALE_NONE)");
