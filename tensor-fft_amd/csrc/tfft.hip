@@ -356,7 +356,7 @@ inline uint32_t gens_grid(uint64_t blocks, uint32_t capacity, uint32_t launch_it
   if (launch_iters) return pick_grid(blocks, static_cast<int>(capacity), plan_iters(launch_iters, 1000000u));
   static const uint32_t gens_env = env_iters("TFFT_GENS", 0);            // experiment knob (debug build only)
   const uint32_t gens = gens_env ? gens_env : gens_dflt;
-  constexpr uint64_t kMinRounds = 8;
+  static const uint64_t kMinRounds = env_iters("TFFT_GENS_MIN_ROUNDS", 8);     // (experiment knob in the debug build; 8 otherwise)
   if (gens > 1 && blocks >= static_cast<uint64_t>(capacity) * gens * kMinRounds) return capacity * gens;
   return static_cast<uint32_t>(std::min<uint64_t>(blocks, capacity));
 }

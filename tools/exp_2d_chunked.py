@@ -1,6 +1,7 @@
 """2D 4096 x 4096 x 64 as the library runs it (two launches over the whole batch) against image-by-image chains (both passes of a
 chunk of images back to back, so that the 64-MiB intermediate image is still in the 256-MiB Infinity Cache when the column pass
-reads it; tools/mall_probe.hip: a producer / consumer copy chain gains 17 % that way).  python tools/exp_2d_chunked.py"""
+reads it; tools/mall_probe.hip: a producer / consumer copy chain gains 17 % that way).
+    python tools/exp_2d_chunked.py [n = 4096] [images = 64] [chunk ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,13 +14,15 @@ if os.environ.get("TFFT_AB_LIB"):            # another build of the library (pat
     capi._LIB_NAME = os.path.abspath(os.environ["TFFT_AB_LIB"])
     capi._lib = None
 
-n, images = 4096, 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+images = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+chunks = [int(v) for v in sys.argv[3:]] or [64, 1, 2, 4, 8]
 half = images * n * n
 x = torch.empty(2 * half, dtype=torch.float16, device="cuda")
 tf.synth_uniform(x[:half], x[half:], n * n, images, batch_stride=n * n)
 y = torch.empty_like(x)
 ref = None
-for chunk in (64, 1, 2, 4, 8):
+for chunk in chunks:
     plan = tf.TfftPlan2D(n, n, chunk, 0)
     ws = torch.empty(plan.workspace_bytes // 2, dtype=torch.float16, device="cuda")
     plan.set_workspace(ws)
