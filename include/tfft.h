@@ -125,7 +125,9 @@ typedef struct tfft_plan_opts {
                            524288) where the 8-wave single-round kernel is the default, and vice versa (default: two-round
                            at row pitches of 256 and 512 columns).
                            Column passes: 131072 = per-wave kernel, 524288 = 4-wave cooperative workgroups,
-                           262144 = no non-temporal accesses, 1048576 = 16-byte stores straight from registers,
+                           262144 = plain (cached) global accesses, 536870912 = non-temporal (streaming) ones; neither:
+                           by the plan's footprint, see tfft_plan_cache_policy(); 1048576 = 16-byte stores straight from
+                           registers,
                            4096 / 8192 = per-wave kernel with LDS-staged stores / hardware sin-cos twiddles.
                            Unknown bits are rejected (TFFT_ERR_ARG), see tfft_variant_check().
                            Timing / debugging aids that give WRONG or partial results are NOT part of this field's
@@ -202,6 +204,13 @@ enum { TFFT_ORDER_NATURAL = 0, TFFT_ORDER_TRANSPOSED = 1 };
 
 /* Host only. N2 of the TRANSPOSED order for length n (0: no two-pass split, natural order is produced). */
 uint64_t tfft_plan_transposed_n2(uint64_t n);
+
+/* Host only. Cache policy tfft_plan_create picks for the column passes of a NATURAL-order plan (n, inner, batch) when the
+ * variant names neither: 1 = plain global accesses (the plan's footprint, 12 bytes per sample for input + output + workspace,
+ * is small enough for the 256-MiB Infinity Cache to hold a useful part of it between the passes), 0 = non-temporal accesses
+ * (larger plans stream; single-kernel lengths and strided axes always do). The thresholds are measured:
+ * profiles/r4_cache_policy.txt. The results do not depend on the policy, only the time does. */
+int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch);
 
 /* Host only: TFFT_OK if `variant` is acceptable to tfft_plan_create for (n, inner): only documented bits, no
  * combination without a compiled kernel, and no WRONG-result debugging bit unless TFFT_DEBUG_VARIANTS=1 is set.

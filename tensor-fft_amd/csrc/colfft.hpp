@@ -29,15 +29,25 @@
 // Streaming hint of the column passes' global accesses (every byte is touched once per pass). -DTFFT_COL_NO_NT builds them as
 // plain accesses: the A/B behind the chunked execution experiments of round 4 (does a non-temporal access keep an intermediate
 // out of the Infinity Cache?).
+// kPlainAcc: a constexpr every kernel that uses these macros defines at its top (template parameter PLAIN, or !NT in the radix-256
+// kernel): plain instead of non-temporal global accesses, for plans whose whole footprint fits the Infinity Cache (tfft.hip
+// cache_policy). A COMPILE-time choice on purpose. A run-time branch was tried first (round 4): identical loads / stores in an
+// if / else are merged by the optimiser, which keeps only the metadata both sides carry and so silently DROPS the non-temporal
+// hint (seen in the ISA: every access came out plain); keeping the sides apart with empty asm statements costs the radix-1024
+// kernel, which sits at 256 VGPRs, 500-700 B of scratch.
 #if defined(TFFT_COL_NO_NT) || defined(TFFT_COL_PLAIN_LOADS)
 #define TFFT_NT_LOAD(p) (*(p))
 #else
-#define TFFT_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define TFFT_NT_LOAD(p) (kPlainAcc ? *(p) : __builtin_nontemporal_load(p))
 #endif
 #if defined(TFFT_COL_NO_NT) || defined(TFFT_COL_PLAIN_STORES)
 #define TFFT_NT_STORE(v, p) (*(p) = (v))
 #else
-#define TFFT_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#define TFFT_NT_STORE(v, p)                         \
+  do {                                              \
+    if (kPlainAcc) *(p) = (v);                      \
+    else __builtin_nontemporal_store(v, p);         \
+  } while (0)
 #endif
 
 namespace colfft {
@@ -116,15 +126,15 @@ enum : int { kTwNone = 0, kTwNext = 1, kTwFourStep = 2 };
 // not profit from the cache the way a contiguous one does). All loads stay non-temporal: the caller's input must not displace
 // the intermediates, and an intermediate is dead once read (plain loads of it: -16 % in the 2D plan, profiles/r4_ab_2d_chunk.txt).
 // -DTFFT_COL_STREAM_ALL = round 3's policy (everything non-temporal), for A/B builds.
-template <int TW, typename V>
-__device__ __forceinline__ void st_pass(V v, V* p) {
 #ifdef TFFT_COL_STREAM_ALL
-  TFFT_NT_STORE(v, p);
+#define TFFT_ST_PASS(TW, v, p) TFFT_NT_STORE(v, p)
 #else
-  if constexpr (TW == kTwFourStep) *p = v;
-  else TFFT_NT_STORE(v, p);
+#define TFFT_ST_PASS(TW, v, p)                      \
+  do {                                              \
+    if ((TW) == kTwFourStep) *(p) = (v);            \
+    else TFFT_NT_STORE(v, p);                       \
+  } while (0)
 #endif
-}
 
 struct cpx {
   float re, im;
@@ -407,6 +417,7 @@ constexpr int kWgLdsBytes = WgGeom<8>::kLds;
 template <int MODE, int TW, bool NT, int W, bool STG = false>
 __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
   static_assert(TW != kTwFourStep || MODE == kColsInRegs, "the four-step twiddle exists for the columns-in-registers form");
+  constexpr bool kPlainAcc = !NT;
   using G = WgGeom<W>;
   constexpr int kPlane = G::kPlane, kRps = G::kRps, kCpr = G::kCpr;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -542,8 +553,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         const u4 vr = *reinterpret_cast<const u4*>(img + 8192 * wave + 1024 * i + 16 * lane);
         const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 8192 * wave + 1024 * i + 16 * lane);
         const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
-        st_pass<TW>(vr, reinterpret_cast<u4*>(c_re + o));
-        st_pass<TW>(vi, reinterpret_cast<u4*>(c_im + o));
+        TFFT_ST_PASS(TW, vr, reinterpret_cast<u4*>(c_re + o));
+        TFFT_ST_PASS(TW, vi, reinterpret_cast<u4*>(c_im + o));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -684,8 +695,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 8192 * wave + 1024 * i + 16 * lane);
         const uint64_t o = (m0 + f) * 256 + 8 * chunk;
         if (NT) {
-          st_pass<TW>(vr, reinterpret_cast<u4*>(o_re + o));
-          st_pass<TW>(vi, reinterpret_cast<u4*>(o_im + o));
+          TFFT_ST_PASS(TW, vr, reinterpret_cast<u4*>(o_re + o));
+          TFFT_ST_PASS(TW, vi, reinterpret_cast<u4*>(o_im + o));
         } else {
           *reinterpret_cast<u4*>(o_re + o) = vr;
           *reinterpret_cast<u4*>(o_im + o) = vi;
@@ -712,8 +723,8 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         }
         const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
         if (NT) {
-          st_pass<TW>(vr, reinterpret_cast<u4*>(o_re + o));
-          st_pass<TW>(vi, reinterpret_cast<u4*>(o_im + o));
+          TFFT_ST_PASS(TW, vr, reinterpret_cast<u4*>(o_re + o));
+          TFFT_ST_PASS(TW, vi, reinterpret_cast<u4*>(o_im + o));
         } else {
           *reinterpret_cast<u4*>(o_re + o) = vr;
           *reinterpret_cast<u4*>(o_im + o) = vi;
@@ -750,8 +761,9 @@ constexpr bool kLut512 = TFFT_LUT512;
 
 // SC: multiply the output by Args::comb_scale in fp32 at the read-out (TFFT_SCALE_ONCE with this pass as the plan's last;
 // otherwise the combine's 1/2 is part of the constant operands and the combine is a plain sum).
-template <int MODE, int TW, bool SC = false>
+template <int MODE, int TW, bool SC = false, bool PLAIN = false>
 __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
+  constexpr bool kPlainAcc = PLAIN;
   static_assert(TW != kTwFourStep || MODE == kColsInRegs, "the four-step twiddle exists for the columns-in-registers form");
   static_assert(!SC || (MODE == kColsInRegs && TW == kTwNone), "the read-out factor exists for a final pass");
   using G = WgGeom<4>;
@@ -957,10 +969,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
         const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
         const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
         const uint64_t o0 = (mb + f) * 512 + k0;
-        st_pass<TW>(s0r, reinterpret_cast<u4*>(c_re + o0));
-        st_pass<TW>(s0i, reinterpret_cast<u4*>(c_im + o0));
-        st_pass<TW>(s1r, reinterpret_cast<u4*>(c_re + o0 + 256));
-        st_pass<TW>(s1i, reinterpret_cast<u4*>(c_im + o0 + 256));
+        TFFT_ST_PASS(TW, s0r, reinterpret_cast<u4*>(c_re + o0));
+        TFFT_ST_PASS(TW, s0i, reinterpret_cast<u4*>(c_im + o0));
+        TFFT_ST_PASS(TW, s1r, reinterpret_cast<u4*>(c_re + o0 + 256));
+        TFFT_ST_PASS(TW, s1i, reinterpret_cast<u4*>(c_im + o0 + 256));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();          // D
@@ -1007,10 +1019,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       if (TW == kTwNone && !SC) {
         // last pass: X = A_0 +- A_1 is the output itself: packed binary16 sums (one correct rounding each, exactly what the
         // fp32 path's sum-then-round gives, in 16 instructions instead of 80)
-        st_pass<TW>(__builtin_bit_cast(u4, ar + br), reinterpret_cast<u4*>(o_re + o0));
-        st_pass<TW>(__builtin_bit_cast(u4, ai + bi), reinterpret_cast<u4*>(o_im + o0));
-        st_pass<TW>(__builtin_bit_cast(u4, ar - br), reinterpret_cast<u4*>(o_re + o1));
-        st_pass<TW>(__builtin_bit_cast(u4, ai - bi), reinterpret_cast<u4*>(o_im + o1));
+        TFFT_ST_PASS(TW, __builtin_bit_cast(u4, ar + br), reinterpret_cast<u4*>(o_re + o0));
+        TFFT_ST_PASS(TW, __builtin_bit_cast(u4, ai + bi), reinterpret_cast<u4*>(o_im + o0));
+        TFFT_ST_PASS(TW, __builtin_bit_cast(u4, ar - br), reinterpret_cast<u4*>(o_re + o1));
+        TFFT_ST_PASS(TW, __builtin_bit_cast(u4, ai - bi), reinterpret_cast<u4*>(o_im + o1));
         continue;
       }
       float x0r[8], x0i[8], x1r[8], x1i[8];
@@ -1075,10 +1087,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft512_wg_kernel(Args a) {
       const u4 s0i = {pk(x0i[0], x0i[1]), pk(x0i[2], x0i[3]), pk(x0i[4], x0i[5]), pk(x0i[6], x0i[7])};
       const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
       const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
-      st_pass<TW>(s0r, reinterpret_cast<u4*>(o_re + o0));
-      st_pass<TW>(s0i, reinterpret_cast<u4*>(o_im + o0));
-      st_pass<TW>(s1r, reinterpret_cast<u4*>(o_re + o1));
-      st_pass<TW>(s1i, reinterpret_cast<u4*>(o_im + o1));
+      TFFT_ST_PASS(TW, s0r, reinterpret_cast<u4*>(o_re + o0));
+      TFFT_ST_PASS(TW, s0i, reinterpret_cast<u4*>(o_im + o0));
+      TFFT_ST_PASS(TW, s1r, reinterpret_cast<u4*>(o_re + o1));
+      TFFT_ST_PASS(TW, s1i, reinterpret_cast<u4*>(o_im + o1));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // D: read out; the next block's copy-in may overwrite the images

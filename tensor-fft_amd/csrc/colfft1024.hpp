@@ -26,8 +26,9 @@ constexpr int kWg1024LdsBytes = kTab1024 + 4 * WgGeom<4>::kPlane;   // 160 KiB
 
 // SC: multiply the output by Args::comb_scale in fp32 at the read-out (TFFT_SCALE_ONCE with this pass as the plan's last:
 // the single 1/N cannot ride on the binary16 operand G_q).
-template <int MODE, int TW, bool SC = false>
+template <int MODE, int TW, bool SC = false, bool PLAIN = false>
 __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
+  constexpr bool kPlainAcc = PLAIN;
   static_assert(TW != kTwFourStep, "the four-step twiddle exists for the radix-256 and radix-512 passes");
   static_assert(!SC || (MODE == kColsInRegs && TW == kTwNone), "the read-out factor exists for a final pass");
   using G = WgGeom<4>;
@@ -122,18 +123,32 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
       const uint8_t* gi = reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off;
       const uint32_t d0 = img_off + 8192 * w4 + 1024 * i, d1 = d0 + kPlaneAll;
       uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\t"
-          "s_mov_b32 m0, %3\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off nt\n\t"
-          "s_mov_b32 m0, %4\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %2, off nt\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
-          : "memory");
+      if (kPlainAcc)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+            : "memory");
+      else
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off nt\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+            : "memory");
       __builtin_amdgcn_sched_barrier(0);       // one address pair at a time (16 pairs up front would cost 64 registers)
     }
   };
@@ -354,10 +369,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
           const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
           const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
           const uint64_t o0 = (mb + f) * 1024 + k0;
-          st_pass<TW>(s0r, reinterpret_cast<u4*>(c_re + o0));
-          st_pass<TW>(s0i, reinterpret_cast<u4*>(c_im + o0));
-          st_pass<TW>(s1r, reinterpret_cast<u4*>(c_re + o0 + 512));
-          st_pass<TW>(s1i, reinterpret_cast<u4*>(c_im + o0 + 512));
+          TFFT_ST_PASS(TW, s0r, reinterpret_cast<u4*>(c_re + o0));
+          TFFT_ST_PASS(TW, s0i, reinterpret_cast<u4*>(c_im + o0));
+          TFFT_ST_PASS(TW, s1r, reinterpret_cast<u4*>(c_re + o0 + 512));
+          TFFT_ST_PASS(TW, s1i, reinterpret_cast<u4*>(c_im + o0 + 512));
           __builtin_amdgcn_sched_barrier(0);     // one chunk at a time (registers)
         }
         return;
@@ -395,10 +410,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
         if (TW == kTwNone && !SC) {
           // last pass: the combine IS the output: packed binary16 sums (one correct rounding each, what the fp32 path's
           // sum-then-round gives, in 16 instructions instead of 80). -i D = (D.im, -D.re).
-          st_pass<TW>(__builtin_bit_cast(u4, j ? ar + bi : ar + br), reinterpret_cast<u4*>(o_re + o0));
-          st_pass<TW>(__builtin_bit_cast(u4, j ? ai - br : ai + bi), reinterpret_cast<u4*>(o_im + o0));
-          st_pass<TW>(__builtin_bit_cast(u4, j ? ar - bi : ar - br), reinterpret_cast<u4*>(o_re + o1));
-          st_pass<TW>(__builtin_bit_cast(u4, j ? ai + br : ai - bi), reinterpret_cast<u4*>(o_im + o1));
+          TFFT_ST_PASS(TW, __builtin_bit_cast(u4, j ? ar + bi : ar + br), reinterpret_cast<u4*>(o_re + o0));
+          TFFT_ST_PASS(TW, __builtin_bit_cast(u4, j ? ai - br : ai + bi), reinterpret_cast<u4*>(o_im + o0));
+          TFFT_ST_PASS(TW, __builtin_bit_cast(u4, j ? ar - bi : ar - br), reinterpret_cast<u4*>(o_re + o1));
+          TFFT_ST_PASS(TW, __builtin_bit_cast(u4, j ? ai + br : ai - bi), reinterpret_cast<u4*>(o_im + o1));
           __builtin_amdgcn_sched_barrier(0);
           continue;
         }
@@ -442,10 +457,10 @@ __global__ __launch_bounds__(kThreads, 2) void colfft1024_wg_kernel(Args a) {
         const u4 s0i = {pk(x0i[0], x0i[1]), pk(x0i[2], x0i[3]), pk(x0i[4], x0i[5]), pk(x0i[6], x0i[7])};
         const u4 s1r = {pk(x1r[0], x1r[1]), pk(x1r[2], x1r[3]), pk(x1r[4], x1r[5]), pk(x1r[6], x1r[7])};
         const u4 s1i = {pk(x1i[0], x1i[1]), pk(x1i[2], x1i[3]), pk(x1i[4], x1i[5]), pk(x1i[6], x1i[7])};
-        st_pass<TW>(s0r, reinterpret_cast<u4*>(o_re + o0));
-        st_pass<TW>(s0i, reinterpret_cast<u4*>(o_im + o0));
-        st_pass<TW>(s1r, reinterpret_cast<u4*>(o_re + o1));
-        st_pass<TW>(s1i, reinterpret_cast<u4*>(o_im + o1));
+        TFFT_ST_PASS(TW, s0r, reinterpret_cast<u4*>(o_re + o0));
+        TFFT_ST_PASS(TW, s0i, reinterpret_cast<u4*>(o_im + o0));
+        TFFT_ST_PASS(TW, s1r, reinterpret_cast<u4*>(o_re + o1));
+        TFFT_ST_PASS(TW, s1i, reinterpret_cast<u4*>(o_im + o1));
         __builtin_amdgcn_sched_barrier(0);
       }
     };

@@ -31,8 +31,9 @@ namespace colfft {
 template <int W>
 constexpr int wg512r_lds_bytes() { return kLdsTable + 2 * WgGeom<W>::kPlane; }
 
-template <int W, bool SC, bool PF = (W == 8)>
+template <int W, bool SC, bool PF = (W == 8), bool PLAIN = false>
 __global__ __launch_bounds__(64 * W, 2) void colfft512r_wg_kernel(Args a) {
+  constexpr bool kPlainAcc = PLAIN;
   using G = WgGeom<W>;
   constexpr int kPlane = G::kPlane, kRps = G::kRps, kCpr = G::kCpr;      // W = 4: 32 KiB, 2 rows per 256-byte super-row, 8 chunks per row
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -104,18 +105,32 @@ __global__ __launch_bounds__(64 * W, 2) void colfft512r_wg_kernel(Args a) {
       const uint8_t* gi = reinterpret_cast<const uint8_t*>(b_im) + off;
       const uint32_t d0 = img_off + 8192 * wave + 1024 * i, d1 = d0 + kPlane;
       uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\t"
-          "s_mov_b32 m0, %3\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off nt\n\t"
-          "s_mov_b32 m0, %4\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %2, off nt\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
-          : "memory");
+      if (kPlainAcc)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+            : "memory");
+      else
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off nt\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
+            : "memory");
     }
   };
 

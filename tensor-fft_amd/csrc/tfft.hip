@@ -60,7 +60,7 @@ inline int ilog2(uint64_t x) {
 constexpr int kVarK4096 = 1 | 2 | 8 | 16;
 constexpr int kVarDebug = 4 | 64 | 128 | 65536 | (15 << 8);
 constexpr int kVarTuner = kVarK4096 | 32 | 4096 | 8192 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 |
-                          8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456;
+                          8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456 | 536870912;
 // The shipped libtfft.so holds NO timing-only kernel, no environment knob and no measurement hook: all of that is compiled
 // only with -DTFFT_DEBUG_KERNELS (tensor-fft_amd/libtfft_debug.so, built on demand for the drivers under tools/), and even
 // there the debugging bits need TFFT_DEBUG_VARIANTS=1 in the environment of the process that creates the plan.
@@ -149,6 +149,7 @@ struct tfft_plan {
   // four-step twiddle of a single column pass (tfft_plan_opts.fourstep_n): w_M^(k (col0 + c)); the w tables below are
   // then built for M instead of n
   uint64_t tw4_modulus = 0, tw4_col0 = 0;
+  bool plain_acc = false;                // column passes with plain instead of non-temporal global accesses (cache_policy())
   k4096::Addr in_map{}, out_map{};       // single-kernel plans: where transform b starts (plain or grouped)
   k4096::OutTw otw{};                    // single-kernel plans: output twiddle of a transposed-input plan's row pass (n_mask = 0: off)
   // TFFT_ORDER_TRANSPOSED input: contiguous N2-point row pass (with that output twiddle) into the workspace, then ONE plain
@@ -563,8 +564,8 @@ template <int MODE, int TW, int W>
 int launch_col_wg_nt(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   // non-temporal copy-in and row stores (default; variant bit 262144 turns them off)
   if (MODE == colfft::kColsOnLanes && !(p->variant & 1048576))   // staged full-row stores (bit 1048576: direct 16-byte pieces)
-    return (p->variant & 262144) ? launch_col_wg<MODE, TW, false, W, true>(p, a, s) : launch_col_wg<MODE, TW, true, W, true>(p, a, s);
-  return (p->variant & 262144) ? launch_col_wg<MODE, TW, false, W>(p, a, s) : launch_col_wg<MODE, TW, true, W>(p, a, s);
+    return p->plain_acc ? launch_col_wg<MODE, TW, false, W, true>(p, a, s) : launch_col_wg<MODE, TW, true, W, true>(p, a, s);
+  return p->plain_acc ? launch_col_wg<MODE, TW, false, W>(p, a, s) : launch_col_wg<MODE, TW, true, W>(p, a, s);
 }
 
 template <int W>
@@ -640,16 +641,16 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     const uint32_t grid = gens_grid(blocks, static_cast<uint32_t>(p->num_cus), p->launch_iters, kGensCol8);
     if (a.ns_f == 1) {
       if (ps.tw_next)
-        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
+        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); }
       else
-        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
+        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); }
     } else {
       if (ps.tw_next)
-        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
+        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNext, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); }
       else if (ps.scale != 1.0f)         // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out
         TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
       else
-        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
+        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); }
     }
     return TFFT_OK;
   }
@@ -660,14 +661,14 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     const uint32_t grid = gens_grid(blocks, static_cast<uint32_t>(p->num_cus), p->launch_iters, kGensCol8);
     if (on_lanes) {
       if (ps.tw_next)
-        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
       else
-        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
     } else {
       if (p->tw4_modulus)
-        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwFourStep>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwFourStep, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwFourStep>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
       else if (ps.tw_next)
-        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNext, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
       else if (((a.pitch == 256 || a.pitch == 512) && a.ns_f % 128 == 0) != ((p->variant & 268435456) != 0)) {
         // last pass of a plan / 2D column pass by the two-round kernel (colfft512r.hpp). A/B in one process on MI355X, 8 GiB per
         // launch (profiles/r3_ab_colfft512r.txt): the 128-column two-round form is 2-4 % faster than the 8-wave single-round
@@ -681,15 +682,17 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
         if (w8 && sc)
           TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, true>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a);
         else if (w8)
-          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, false>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a);
+          { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, false, true, true>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a);
+            else TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, false>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a); }
         else if (sc)
           TFFT_LAUNCH((colfft::colfft512r_wg_kernel<4, true>), dim3(grid2), dim3(256), colfft::wg512r_lds_bytes<4>(), s, a);
         else
-          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<4, false>), dim3(grid2), dim3(256), colfft::wg512r_lds_bytes<4>(), s, a);
+          { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512r_wg_kernel<4, false, false, true>), dim3(grid2), dim3(256), colfft::wg512r_lds_bytes<4>(), s, a);
+            else TFFT_LAUNCH((colfft::colfft512r_wg_kernel<4, false>), dim3(grid2), dim3(256), colfft::wg512r_lds_bytes<4>(), s, a); }
       } else if (ps.scale != 1.0f)       // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out
         TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
       else
-        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
+        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
     }
     return TFFT_OK;
   }
@@ -1076,6 +1079,27 @@ int apply_scale_mode(tfft_plan* p, const InternalOpts& io, k4096::TableScale& ts
 
 int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts* opts, const InternalOpts& io, tfft_plan** out);
 
+// Cache policy of a multi-pass plan's column passes from its footprint F (input + output + workspace = 3 x 4 B per sample): what
+// fits the Infinity Cache (256 MiB) or comes close should stay in it - plain accesses: a pass then finds part of what the pass
+// before it (or the caller) wrote still in the cache - what is much larger must stream (non-temporal: a line that is evicted
+// before it is used again only displaces one that would have been hit). Measured with tools/scan_cache_policy.py, both on one data
+// set again and again and on a ring of buffers of > 1 GiB (profiles/r4_cache_policy.txt), plain against streaming accesses:
+//   two passes of radix 512 / 1024 (2^18..2^20): -3..-24 % for every F <= 384 MiB, +3..+9 % at 768 MiB
+//   three passes (2^21..2^25): -2..-19 % for 192 and 384 MiB, +12..+19 % at 48 MiB, +-3 % at 96 MiB, +3..+10 % from 768 MiB on
+//   radix-256 passes (2^16, 2^17): 0..+34 % (never better on the ring of buffers): they keep streaming
+//   column pass of a transposed-output plan: -1..-15 % on one data set, +-3 % on the ring, for 192 and 384 MiB; worse outside
+// Strided-axis plans (inner > 1: the 2D plan's and the distributed transform's column passes, transposed-input plans) keep the
+// streaming policy they were tuned with; the transposed-output plan decides for its column sub-plan with footprint_policy().
+constexpr uint64_t kMiB = 1ull << 20;
+inline bool footprint_policy(uint64_t samples, uint64_t lo_mib) {
+  const uint64_t f = samples * 12;
+  return f >= lo_mib * kMiB && f <= 512 * kMiB;
+}
+inline bool cache_policy(uint64_t n, uint64_t inner, uint64_t batch) {
+  if (inner != 1 || n < (1ull << 18) || batch > (1ull << 40) / n) return false;
+  return footprint_policy(n * batch, n <= (1ull << 20) ? 0 : 128);
+}
+
 // Transforms per chunk of a transposed-order plan: about 512 MiB of intermediate (measured, profiles/r4_chunked_transposed.txt:
 // 2^20 x 1024 in chunks of 256 / 128 / 64 / 32 transforms 368 / 375 / 374 / 349 Gsamples/s against 348 for the whole batch; 2^24 x
 // 64 in chunks of 16 / 8 / 4: 322 / 319 / 309 against 311), never chunks so short that a launch has less than 2^26 samples
@@ -1098,11 +1122,12 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   co.preserve_input = 1;
   // tuner bits: the column-pass bits go to the column sub-plan, the single-kernel bits of the N2 kernel to the row sub-plan;
   // everything else has no meaning for this plan shape and is refused instead of being dropped silently
-  constexpr int kColBits = 262144 | 524288, kRowBits = kVarK4096 | 1048576;
+  constexpr int kColBits = 262144 | 524288 | 536870912, kRowBits = kVarK4096 | 1048576;
   if (p->variant & ~(kColBits | kRowBits))
     return fail(TFFT_ERR_ARG, "tfft_plan_opts.variant " + std::to_string(p->variant) + ": a TFFT_ORDER_TRANSPOSED plan honours only the "
-                              "column-pass bits 262144 / 524288 and the single-kernel bits 1 / 2 / 8 / 16 / 1048576");
+                              "column-pass bits 262144 / 524288 / 536870912 and the single-kernel bits 1 / 2 / 8 / 16 / 1048576");
   co.variant = (p->variant & kColBits) | (n1 == 512 ? 67108864 : 0);
+  if (!(p->variant & (262144 | 536870912)) && footprint_policy(n * transposed_chunk(n, p->batch), 128)) co.variant |= 262144;
   co.scale = mode == TFFT_SCALE_SEQUENTIAL ? TFFT_SCALE_SEQUENTIAL : TFFT_SCALE_NONE;
   co.fourstep_n = n;
   co.launch_iters = p->launch_iters;
@@ -1164,10 +1189,10 @@ int create_transposed_in(tfft_plan* p, int device_id) {
   if (p->scale_mode == TFFT_SCALE_ONCE)
     return fail(TFFT_ERR_ARG, "TFFT_SCALE_ONCE is not available with transposed-order input: the plan's last fp32 multiply lies in "
                               "front of its last stage (use TFFT_SCALE_SEQUENTIAL or TFFT_SCALE_NONE)");
-  constexpr int kColBits = 262144 | 524288;
+  constexpr int kColBits = 262144 | 524288 | 536870912;
   if (p->variant & ~kColBits)
     return fail(TFFT_ERR_ARG, "tfft_plan_opts.variant " + std::to_string(p->variant) + ": a plan with transposed-order input honours only the "
-                              "column-pass bits 262144 / 524288");
+                              "column-pass bits 262144 / 524288 / 536870912");
   tfft_plan_opts ro = TFFT_PLAN_OPTS_INIT;
   ro.in_batch_stride = n2;
   ro.out_batch_stride = n2;
@@ -1266,6 +1291,9 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   p->variant = pvariant;
   p->launch_iters = opts ? opts->launch_iters : 0;
   p->scale_mode = scale_mode;
+  // cache policy of the column passes: variant bit 262144 = plain accesses, 536870912 = non-temporal (streaming) accesses,
+  // neither = by the plan's footprint (cache_policy)
+  p->plain_acc = (pvariant & 262144) ? true : ((pvariant & 536870912) ? false : cache_policy(n, inner, batch));
   p->tw4_modulus = tw4;
   p->tw4_col0 = opts ? opts->fourstep_col0 : 0;
   p->in_map = k4096::Addr{in_stride, io.group_shift ? io.in_gstride : in_stride, io.group_shift, (1u << io.group_shift) - 1u};
@@ -1410,6 +1438,11 @@ uint64_t tfft_plan_transposed_n2(uint64_t n) {
   // reachable with N1 = 512 (the N = 4096 kernel is the fastest second pass)
   const int lg2 = (lg == 21 || lg == 24) ? lg - 9 : lg - 8;
   return uint64_t{1} << lg2;
+}
+
+int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch) {
+  if (!is_pow2(n) || !inner || !batch) return 0;
+  return cache_policy(n, inner, batch) ? 1 : 0;
 }
 
 int tfft_variant_check(uint64_t n, uint64_t inner, int variant) {

@@ -400,3 +400,31 @@ def test_c_abi_spectral_filter_example():
         print(r.stdout, r.stderr)
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
         assert "forward 2 passes, inverse 2 passes" in r.stdout
+
+
+@pytest.mark.parametrize("lg,batch,order", [(18, 4, "natural"), (19, 3, "natural"), (20, 8, "natural"), (21, 8, "natural"),
+                                            (22, 4, "natural"), (24, 1, "natural"), (17, 8, "natural"),
+                                            (20, 16, "transposed"), (22, 4, "transposed"), (24, 1, "transposed"),
+                                            (20, 16, "transposed_in")])
+def test_cache_policy_changes_the_time_never_the_result(tf, lg, batch, order):
+    """The column passes exist with plain and with non-temporal global accesses (variant bits 262144 / 536870912; neither = the
+    library picks by the plan's footprint, tfft_plan_cache_policy): same arithmetic, so the three plans must agree to the bit."""
+    import torch
+
+    n = 1 << lg
+    x = torch.empty(batch * 2 * n, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x, x[n:], n, batch)
+    kw = {"natural": {}, "transposed": {"output_order": "transposed"}, "transposed_in": {"input_order": "transposed"}}[order]
+    outs = []
+    for v in (0, 262144, 536870912):
+        plan = tf.TfftPlan(n, batch, 0, variant=v, preserve_input=True, **kw)
+        ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+        if plan.workspace_bytes:
+            plan.set_workspace(ws)
+        y = torch.full_like(x, float("nan"))
+        plan.exec(x, x[n:], y, y[n:])
+        torch.cuda.synchronize()
+        outs.append(y.view(torch.int16))
+        plan.close()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert not torch.isnan(outs[0].view(torch.float16)).any()

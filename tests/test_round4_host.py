@@ -86,6 +86,24 @@ def test_dist_geometry_is_filled_up_to_the_callers_size():
         assert "struct_size" in capi.last_error() and bytes(buf2[4:]) == b"\xee" * (n - 4)
 
 
+def test_cache_policy_follows_the_footprint():
+    """tfft_plan_cache_policy (host only): plain accesses where the measured scan (profiles/r4_cache_policy.txt) found them
+    faster, streaming everywhere else. Footprint = 12 bytes per sample."""
+    P = tf.plan_cache_policy
+    # two passes of radix 512 / 1024: every footprint up to 512 MiB
+    assert P(1 << 18, 1, 1) and P(1 << 20, 1, 1) and P(1 << 20, 1, 32) and P(1 << 19, 1, 64)
+    assert not P(1 << 20, 1, 64) and not P(1 << 20, 1, 1024) and not P(1 << 18, 1, 256)
+    assert P(1 << 20, 1, 42) and not P(1 << 20, 1, 43)               # 504 MiB / 516 MiB
+    # three passes: 128..512 MiB
+    assert not P(1 << 21, 1, 1) and not P(1 << 22, 1, 2) and P(1 << 22, 1, 4) and P(1 << 24, 1, 1) and P(1 << 25, 1, 1)
+    assert not P(1 << 24, 1, 4) and not P(1 << 26, 1, 1) and not P(1 << 30, 1, 1)
+    # radix-256 passes, single-kernel lengths, strided axes: streaming
+    assert not P(1 << 16, 1, 256) and not P(1 << 17, 1, 128) and not P(4096, 1, 4096) and not P(256, 1, 1)
+    assert not P(512, 4096, 8) and not P(1 << 20, 64, 1)
+    # nonsense in, 0 out (no error channel)
+    assert not P(3 << 18, 1, 1) and not P(1 << 20, 0, 1) and not P(1 << 20, 1, 0) and not P(1 << 20, 1, 1 << 62)
+
+
 def test_header_and_binding_agree_on_the_layouts():
     """ctypes mirrors of the two versioned structs against the header, compiled by the host compiler."""
     import subprocess
