@@ -1616,6 +1616,9 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
       co.out_batch_stride = rows * cols;
       co.inner = cols;
       co.variant = 67108864;
+#ifdef TFFT_2D_COL_VARIANT     // A/B knob: cache-policy bits (262144 / 536870912) for the column pass
+      co.variant |= TFFT_2D_COL_VARIANT;
+#endif
 #ifdef TFFT_2D_CHUNK           // A/B knob
       constexpr uint64_t kChunkImages = TFFT_2D_CHUNK;
 #else

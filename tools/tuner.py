@@ -30,14 +30,16 @@ def candidates(n):
     the single-pass kernel (2^13..2^15); 8388608 = no radix-512 column passes; 33554432 = no radix-1024 column passes; 134217728 = among the
     splits with the fewest passes, the one with the most wide (radix-1024, then radix-512) passes; 268435456 = a final radix-512
     pass by the OTHER of its two kernels (include/tfft.h: the two-round kernel of colfft512r.hpp with 8-wave workgroups and
-    128-column tiles where the single-round kernel is the default, and vice versa; 4-wave workgroups only together with 524288)."""
+    128-column tiles where the single-round kernel is the default, and vice versa; 4-wave workgroups only together with 524288);
+    262144 / 536870912 = plain / non-temporal global accesses in the column passes whatever the footprint (default: by footprint,
+    tfft_plan_cache_policy)."""
     if n == 4096:
         return [16, 2, 10, 8, 1]
     if n < 8192:
         return [0, 32]
     if n <= 32768:
         return [0, 16777216, 16777216 | 8388608, 32]
-    return [0, 32, 524288, 2097152, 1048576, 8388608, 33554432, 8388608 | 33554432, 134217728, 268435456]
+    return [0, 32, 524288, 2097152, 1048576, 8388608, 33554432, 8388608 | 33554432, 134217728, 268435456, 262144, 536870912]
 
 
 def iters_candidates():
