@@ -212,6 +212,14 @@ uint64_t tfft_plan_transposed_n2(uint64_t n);
  * profiles/r4_cache_policy.txt. The results do not depend on the policy, only the time does. */
 int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch);
 
+/* Host only. The planner bits tfft_plan_create gives a NATURAL-order plan whose caller left `variant` at 0: 0 when the work
+ * (n * batch samples) fills the chip - the splits behind variant 0 were measured at 2^30 samples per launch - and otherwise
+ * the bits of the split with more, smaller workgroups (a single 2^20-point transform is 16 workgroups of the radix-1024 kernel
+ * on 256 CUs: 40 us; as 256 x 256 x 16 it takes 24 us). 2^18 ... 2^21 only; measured limits: profiles/r4_small_batch_scan.txt.
+ * tfft_plan_describe(n, inner, tfft_plan_default_variant(n, inner, batch), ...) is the decomposition such a plan gets. A caller
+ * that names any variant bit itself gets exactly that variant. */
+int tfft_plan_default_variant(uint64_t n, uint64_t inner, uint64_t batch);
+
 /* Host only: TFFT_OK if `variant` is acceptable to tfft_plan_create for (n, inner): only documented bits, no
  * combination without a compiled kernel, and no WRONG-result debugging bit unless TFFT_DEBUG_VARIANTS=1 is set.
  * CreatePlan(N, tuner_file) of the shims runs it on the file's sixth column. */

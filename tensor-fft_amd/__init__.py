@@ -16,7 +16,7 @@ Two layers, both thin:
   meaning and error behaviour, on top of :mod:`.capi`. PyTorch supplies device
   memory and streams only.
 """
-from .capi import (TfftError, TfftPlan, TfftPlan2D, device_check, lib_path, load_library, plan_cache_policy, plan_describe,  # noqa: F401
+from .capi import (TfftError, TfftPlan, TfftPlan2D, device_check, lib_path, load_library, plan_cache_policy, plan_default_variant, plan_describe,  # noqa: F401
                    ref_create_plan, synth_uniform, transposed_n2, variant_check)
 from .reference_api import (  # noqa: F401
     ComputeFFT,
@@ -31,7 +31,7 @@ from .reference_api import (  # noqa: F401
 )
 
 __all__ = [
-    "TfftError", "TfftPlan", "TfftPlan2D", "device_check", "lib_path", "load_library", "plan_cache_policy", "plan_describe", "ref_create_plan",
+    "TfftError", "TfftPlan", "TfftPlan2D", "device_check", "lib_path", "load_library", "plan_cache_policy", "plan_default_variant", "plan_describe", "ref_create_plan",
     "synth_uniform", "transposed_n2", "variant_check",
     "ComputeFFT", "CreatePlan", "DataBatchHandler", "DataHandler", "GetMaxNoOptInSharedMem",
     "Mode_256", "Mode_4096", "Plan", "PlanWorksOnDevice",

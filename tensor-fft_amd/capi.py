@@ -19,7 +19,7 @@ SYMBOLS = [
     "tfft_last_error", "tfft_version", "tfft_permute_twiddle", "tfft_exec_inverse", "tfft_deinterleave", "tfft_interleave",
     "tfft_plan2d_create", "tfft_plan2d_destroy", "tfft_plan2d_num_launches", "tfft_plan2d_workspace_bytes",
     "tfft_plan2d_set_workspace", "tfft_plan2d_exec", "tfft_plan2d_exec_inverse", "tfft_plan_describe",
-    "tfft_variant_check", "tfft_plan_transposed_n2", "tfft_plan_cache_policy", "tfft_synth_uniform",
+    "tfft_variant_check", "tfft_plan_transposed_n2", "tfft_plan_cache_policy", "tfft_plan_default_variant", "tfft_synth_uniform",
     "tfft_dist_geometry_query", "tfft_dist_unique_id", "tfft_dist_comm_create", "tfft_dist_comm_create_all",
     "tfft_dist_comm_destroy", "tfft_dist_group_start", "tfft_dist_group_end", "tfft_dist_plan_create",
     "tfft_dist_plan_destroy", "tfft_dist_plan_geometry", "tfft_dist_plan_buffers", "tfft_dist_plan_set_buffers",
@@ -178,6 +178,8 @@ def load_library():
     L.tfft_plan_transposed_n2.argtypes = [u64]
     L.tfft_plan_cache_policy.restype = ci
     L.tfft_plan_cache_policy.argtypes = [u64, u64, u64]
+    L.tfft_plan_default_variant.restype = ci
+    L.tfft_plan_default_variant.argtypes = [u64, u64, u64]
     L.tfft_synth_uniform.restype = ci
     L.tfft_synth_uniform.argtypes = [vp, vp, u64, u64, u64, u64, u64, vp]
     L.tfft_plan_kernel_name.restype = ctypes.c_char_p
@@ -270,6 +272,12 @@ def transposed_n2(n):
 def plan_cache_policy(n, inner=1, batch=1):
     """tfft_plan_cache_policy: True = the column passes of this natural-order plan use plain (cached) accesses. Host only."""
     return bool(load_library().tfft_plan_cache_policy(int(n), int(inner), int(batch)))
+
+
+def plan_default_variant(n, inner=1, batch=1):
+    """tfft_plan_default_variant: the planner bits a variant-0 natural-order plan of this shape gets (0 unless the work is too small
+    to fill the chip with the large-batch split). Host only."""
+    return int(load_library().tfft_plan_default_variant(int(n), int(inner), int(batch)))
 
 
 def ref_create_plan(fft_length, mode=0, base_fft_warps_per_block=8, r16_warps_per_block=8, r2_blocksize=256):

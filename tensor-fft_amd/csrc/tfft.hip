@@ -1095,6 +1095,30 @@ inline bool footprint_policy(uint64_t samples, uint64_t lo_mib) {
   const uint64_t f = samples * 12;
   return f >= lo_mib * kMiB && f <= 512 * kMiB;
 }
+// The default splits (kColSplit) were measured at 2^30 samples per launch, where every pass has thousands of workgroups. A plan
+// of a few transforms is another regime: the radix-1024 kernel and the two-round radix-512 kernel take 65536 samples per
+// workgroup, so ONE 2^20-point transform is 16 workgroups on 256 CUs. Below the measured limits the planner bits that give more,
+// smaller workgroups are added to a default (variant 0) plan (tools/scan_small_batch.py, profiles/r4_small_batch_scan.txt; times
+// of executions back to back on one stream):
+//   2^18: the single-round radix-512 kernel for the final pass (64-column tiles)    x 1: 26.4 -> 19.7 us, x 16: 32.5 -> 28.4 us
+//         then, to 2^24 samples, 4-wave workgroups                                   x 32: 38.5 -> 33.3 us, x 64: 57.9 -> 52.1 us
+//   2^19: 256 x 256 x 8 instead of 512 x 1024                                        x 1: 27.4 -> 22.0 us, x 4: 31.6 -> 29.2 us
+//   2^20: 256 x 256 x 16 instead of 1024 x 1024                                      x 1: 40.1 -> 24.1 us, x 4: 48.8 -> 38.1 us
+//   2^21: 256 x 256 x 32 instead of 512 x 512 x 8                                    x 1: 35.1 -> 30.4 us
+// Only variant 0 is touched: a caller (or tuner file) that names any bit gets exactly what it names.
+inline int small_work_variant(uint64_t n, uint64_t inner, uint64_t batch) {
+  if (inner != 1 || !is_pow2(n) || batch == 0 || batch > (1ull << 30)) return 0;
+  const int lg = ilog2(n);
+  if (lg < 18 || lg > 21) return 0;
+  const uint64_t work = n * batch;
+  switch (lg) {
+    case 18: return work <= (1ull << 22) ? 268435456 : (work <= (1ull << 24) ? 524288 : 0);
+    case 19: return work <= (1ull << 21) ? 33554432 : 0;
+    case 20: return work <= (1ull << 23) ? 33554432 : 0;
+    default: return work <= (1ull << 21) ? 8388608 : 0;
+  }
+}
+
 inline bool cache_policy(uint64_t n, uint64_t inner, uint64_t batch) {
   if (inner != 1 || n < (1ull << 18) || batch > (1ull << 40) / n) return false;
   return footprint_policy(n * batch, n <= (1ull << 20) ? 0 : 128);
@@ -1271,6 +1295,10 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   }
   int pvariant = opts ? opts->variant : 0;
   if (tw4 && n == 512) pvariant |= 67108864;    // one radix-512 pass
+  // the default plan of a caller-facing, natural-order transform that does not fill the chip: the split with more workgroups
+  if (pvariant == 0 && !tw4 && order == TFFT_ORDER_NATURAL && in_order == TFFT_ORDER_NATURAL && io.group_shift == 0 && !io.rows2d &&
+      io.in_seg_len == 0 && io.otw_n == 0)
+    pvariant = small_work_variant(n, inner, batch);
   int rc = check_variant(n, inner, pvariant);
   if (rc) return rc;
   if (tw4 && (pvariant & (32 | 131072 | 4096 | 8192)))
@@ -1443,6 +1471,11 @@ uint64_t tfft_plan_transposed_n2(uint64_t n) {
 int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch) {
   if (!is_pow2(n) || !inner || !batch) return 0;
   return cache_policy(n, inner, batch) ? 1 : 0;
+}
+
+int tfft_plan_default_variant(uint64_t n, uint64_t inner, uint64_t batch) {
+  if (!is_pow2(n) || !inner || !batch) return 0;
+  return small_work_variant(n, inner, batch);
 }
 
 int tfft_variant_check(uint64_t n, uint64_t inner, int variant) {

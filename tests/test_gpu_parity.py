@@ -402,7 +402,10 @@ def test_radix1024_column_pass(tf, torch, orc, lg, batch):
     read-outs; both output forms, with and without the next pass's twiddles) against the oracle's fp64 DFT / N (2^28: against
     hipFFT complex64 on the device), and against the plan without it (variant bit 33554432), to fp16 rounding."""
     n = 1 << lg
-    plan = tf.TfftPlan(n, batch, 0)
+    # a few 2^19 / 2^20-point transforms default to the split with more workgroups (tfft_plan_default_variant, round 4): naming
+    # the cache-policy bit (536870912 = streaming, 262144 = plain accesses) asks for the large-batch split, the radix-1024 one
+    wide = 536870912 if lg <= 20 else 0
+    plan = tf.TfftPlan(n, batch, 0, variant=wide)
     other = tf.TfftPlan(n, batch, 0, variant=33554432)
     assert plan.num_launches == other.num_launches - 1
     assert "col:1024" in tf.plan_describe(n, 1, 0) and "col:1024" not in tf.plan_describe(n, 1, 33554432)
@@ -423,11 +426,13 @@ def test_radix1024_column_pass(tf, torch, orc, lg, batch):
     rng = np.random.default_rng(lg + batch)
     re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
     im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
-    gr, gi = _run(tf, torch, re, im)
+    gr, gi = _run(tf, torch, re, im, variant=wide)
     exact = _c(*orc.dft64(re, im))
     got = _c(gr, gi)
     assert np.isfinite(got).all()
     assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= REL_L2_TOL
+    qr, qi = _run(tf, torch, re, im, variant=262144)                  # the same kernels with plain accesses: the same bits
+    assert np.array_equal(qr.view(np.uint16), gr.view(np.uint16)) and np.array_equal(qi.view(np.uint16), gi.view(np.uint16))
     pr, pi = _run(tf, torch, re, im, variant=33554432)
     ref = _c(pr, pi)
     assert np.abs(got - exact).max() <= 1.5 * np.abs(ref - exact).max() + 2.0 ** -11 * np.abs(exact).max()
@@ -435,7 +440,7 @@ def test_radix1024_column_pass(tf, torch, orc, lg, batch):
     f0 = (5 * n) // 7
     t = np.arange(n)
     tone = np.exp(2j * np.pi * f0 * t / n)
-    tr, ti = _run(tf, torch, tone.real.astype(np.float16)[None], tone.imag.astype(np.float16)[None])
+    tr, ti = _run(tf, torch, tone.real.astype(np.float16)[None], tone.imag.astype(np.float16)[None], variant=wide)
     spec = _c(tr, ti)[0]
     assert abs(spec[f0] - 1.0) <= 2e-3
     spec[f0] = 0

@@ -402,7 +402,7 @@ def test_c_abi_spectral_filter_example():
         assert "forward 2 passes, inverse 2 passes" in r.stdout
 
 
-@pytest.mark.parametrize("lg,batch,order", [(18, 4, "natural"), (19, 3, "natural"), (20, 8, "natural"), (21, 8, "natural"),
+@pytest.mark.parametrize("lg,batch,order", [(18, 32, "natural"), (19, 12, "natural"), (20, 16, "natural"), (21, 8, "natural"),
                                             (22, 4, "natural"), (24, 1, "natural"), (17, 8, "natural"),
                                             (20, 16, "transposed"), (22, 4, "transposed"), (24, 1, "transposed"),
                                             (20, 16, "transposed_in")])
@@ -428,3 +428,38 @@ def test_cache_policy_changes_the_time_never_the_result(tf, lg, batch, order):
         plan.close()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert not torch.isnan(outs[0].view(torch.float16)).any()
+
+
+@pytest.mark.parametrize("lg,batch", [(18, 1), (18, 16), (18, 32), (18, 64), (18, 128), (19, 1), (19, 4), (19, 8), (20, 1), (20, 8), (20, 16), (21, 1), (21, 2)])
+def test_small_work_default_split_against_the_oracle_and_the_large_batch_split(tf, orc, lg, batch):
+    """A variant-0 plan that does not fill the chip takes the split with more workgroups (tfft_plan_default_variant). Either split
+    must be within the stated tolerance of the fp64 oracle, and the default plan must BE the variant it reports."""
+    import torch
+
+    n = 1 << lg
+    x = torch.empty(batch * 2 * n, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x, x[n:], n, batch)
+    dv = tf.plan_default_variant(n, 1, batch)
+    outs = {}
+    for name, v in (("default", 0), ("reported", dv), ("large-batch split", 536870912)):
+        plan = tf.TfftPlan(n, batch, 0, variant=v, preserve_input=True)
+        ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+        if plan.workspace_bytes:
+            plan.set_workspace(ws)
+        y = torch.full_like(x, float("nan"))
+        plan.exec(x, x[n:], y, y[n:])
+        torch.cuda.synchronize()
+        outs[name] = y.cpu().numpy().reshape(batch, 2, n)
+        if name == "default":
+            assert plan.num_launches == len(tf.plan_describe(n, 1, dv).split())
+        plan.close()
+    if dv:
+        assert np.array_equal(outs["default"].view(np.uint16), outs["reported"].view(np.uint16))
+    xin = x.cpu().numpy().reshape(batch, 2, n)
+    for b in {0, batch - 1}:
+        er, ei = orc.dft64(xin[b:b + 1, 0], xin[b:b + 1, 1])                   # fp64 DFT(x) / N, the plan's scaling
+        exact = er[0] + 1j * ei[0]
+        for name in ("default", "large-batch split"):
+            got = outs[name][b, 0].astype(np.float64) + 1j * outs[name][b, 1].astype(np.float64)
+            rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+            assert rel <= 1.5e-3, (name, lg, batch, b, rel)

@@ -104,6 +104,25 @@ def test_cache_policy_follows_the_footprint():
     assert not P(3 << 18, 1, 1) and not P(1 << 20, 0, 1) and not P(1 << 20, 1, 0) and not P(1 << 20, 1, 1 << 62)
 
 
+def test_small_work_gets_the_split_with_more_workgroups():
+    """tfft_plan_default_variant (host only): what variant 0 means for a natural-order plan that does not fill the chip
+    (profiles/r4_small_batch_scan.txt); from the measured limits on, and for every other length, it is 0."""
+    V, D = tf.plan_default_variant, tf.plan_describe
+    assert V(1 << 20, 1, 1) == 33554432 and V(1 << 20, 1, 8) == 33554432 and V(1 << 20, 1, 16) == 0 and V(1 << 20, 1, 1024) == 0
+    assert D(1 << 20, 1, V(1 << 20, 1, 1)) == "col:256+tw col:256+tw autosort:16-tw" and D(1 << 20, 1, V(1 << 20, 1, 1024)) == "col:1024+tw col:1024"
+    assert V(1 << 19, 1, 4) == 33554432 and V(1 << 19, 1, 8) == 0
+    assert D(1 << 19, 1, V(1 << 19, 1, 1)) == "col:256+tw col:256+tw autosort:8-tw"
+    assert V(1 << 18, 1, 16) == 268435456 and V(1 << 18, 1, 32) == 524288 and V(1 << 18, 1, 64) == 524288 and V(1 << 18, 1, 128) == 0
+    assert D(1 << 18, 1, V(1 << 18, 1, 1)) == "col:512+tw col:512"            # same split, the other radix-512 kernel
+    assert V(1 << 21, 1, 1) == 8388608 and V(1 << 21, 1, 2) == 0
+    assert D(1 << 21, 1, V(1 << 21, 1, 1)) == "col:256+tw col:256+tw autosort:32-tw"
+    for lg in (8, 12, 16, 17, 22, 24, 26):
+        assert V(1 << lg, 1, 1) == 0
+    assert V(1 << 20, 64, 1) == 0 and V(3 << 19, 1, 1) == 0 and V(1 << 20, 1, 0) == 0
+    for lg, b in ((18, 1), (18, 64), (19, 4), (20, 8), (21, 1)):                          # every value it returns is a variant the library accepts
+        capi.variant_check(1 << lg, 1, V(1 << lg, 1, b))
+
+
 def test_header_and_binding_agree_on_the_layouts():
     """ctypes mirrors of the two versioned structs against the header, compiled by the host compiler."""
     import subprocess
