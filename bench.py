@@ -211,7 +211,10 @@ def other_configs(torch, tf, orc, device):
              ("configs[2]_n2^20_x_1024", 1 << 20, 1024, "natural"),
              ("configs[2]_n2^20_x_1024_transposed_order", 1 << 20, 1024, "transposed"),
              ("configs[2]_n2^20_x_1024_transposed_input", 1 << 20, 1024, "transposed_in"),
-             ("n2^24_x_16", 1 << 24, 16, "natural"), ("n2^24_x_16_transposed_input", 1 << 24, 16, "transposed_in"), ("configs[4b]_single_gpu_n2^26_x_1", 1 << 26, 1, "natural"))
+             ("n2^24_x_16", 1 << 24, 16, "natural"), ("n2^24_x_16_transposed_input", 1 << 24, 16, "transposed_in"), ("configs[4b]_single_gpu_n2^26_x_1", 1 << 26, 1, "natural"),
+             # work that does not fill the chip (the reference's single-transform benchmark, FFTBenchSinlge.cu): the planner's
+             # small-work split and the footprint cache policy (tfft_plan_default_variant, tfft_plan_cache_policy)
+             ("single_n2^20", 1 << 20, 1, "natural"), ("n2^20_x_16", 1 << 20, 16, "natural"))
     def guarded(name, fn):
         """One failure policy for every entry: a failed check or an exception becomes {"error": ...} under the entry's name, the
         other entries and the headline line are unaffected, and main() exits non-zero after printing the line."""

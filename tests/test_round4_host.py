@@ -260,6 +260,6 @@ def test_bench_side_entries_share_one_failure_policy(monkeypatch, capsys):
         cuda = FakeTorch.cuda
 
     out = bench.other_configs(T, FakeTf, None, 0)
-    assert len(out) == 11 and all("error" in v and "stub" in v["error"] for v in out.values()), out
-    assert len(calls) == 11                                        # every entry was attempted
+    assert len(out) == 13 and all("error" in v and "stub" in v["error"] for v in out.values()), out
+    assert len(calls) == 13                                        # every entry was attempted
     assert "other_configs[configs[3]_2d_4096x4096_x_64]" in capsys.readouterr().err
