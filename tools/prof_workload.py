@@ -12,7 +12,7 @@ of every kernel's dispatches) from what they fold.
     c2t     configs[2] with the transposed-output order (two passes); c2ti: with the transposed-input order
     c3      BASELINE configs[3]   2D 4096 x 4096 x 64             (fft4096r_kernel<8,true> + colfft512_wg_kernel)
     n8192 / n16384 / n32768       2^28 samples                    (fft4096r_kernel<R>)
-    n65536, n262144, n2^26 ...    any "nLEN[:batch]"
+    n65536, n262144, n2^26 ...    any "nLEN[:batch[:variant]]"
 """
 import os
 import sys
@@ -72,6 +72,6 @@ elif name.startswith("n"):
     f = name[1:].split(":")
     n = (1 << int(f[0][2:])) if f[0].startswith("2^") else int(f[0])
     b = int(f[1]) if len(f) > 1 else max(1, (1 << 28) // n)
-    run1d(n, b)
+    run1d(n, b, **({"variant": int(f[2])} if len(f) > 2 else {}))
 else:
     raise SystemExit(f"unknown workload {name}")
