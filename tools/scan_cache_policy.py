@@ -3,7 +3,7 @@ plain accesses (variant bit 262144) and the library's own choice (variant 0), in
 Two situations per shape: "hot" = the same buffers again and again (what a caller that iterates on one data set sees: a footprint
 below the 256-MiB Infinity Cache can stay in it), "cold" = a ring of buffer sets of > 1 GiB in total (every execution finds its
 input in HBM).
-    [ORDER=transposed | IN_ORDER=transposed] python tools/scan_cache_policy.py N:batch [N:batch ...]"""
+    [ORDER=transposed | IN_ORDER=transposed] [POLICIES=name=variant,...] python tools/scan_cache_policy.py N:batch [N:batch ...]"""
 import os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +13,8 @@ g.build()
 import tensor_fft_amd as tf
 
 POL = (("stream", 536870912), ("plain", 262144), ("default", 0))
+if os.environ.get("POLICIES"):        # e.g. POLICIES=stream=10,plain=2,default=0 for the N = 4096 kernel (its non-temporal bit is 8)
+    POL = tuple((kv.split("=")[0], int(kv.split("=")[1])) for kv in os.environ["POLICIES"].split(","))
 KW = dict(output_order=os.environ.get("ORDER", "natural"), input_order=os.environ.get("IN_ORDER", "natural"))
 for spec in sys.argv[1:]:
     n, b = (int(v) for v in spec.split(":"))
@@ -55,6 +57,6 @@ for spec in sys.argv[1:]:
     med = {k: statistics.median(v) for k, v in res.items()}
     print(f"N=2^{n.bit_length() - 1:2d} batch={b:5d} footprint {foot:7.0f} MiB launches={plans[0][1].num_launches} ring={sets:4d}: " +
           "  ".join(f"{mode} " + " / ".join(f"{med[(name, mode)]:7.1f}" for name, _, _ in plans) for mode in ("hot", "cold")) +
-          "  us (stream / plain / default)", flush=True)
+          "  us (" + " / ".join(name for name, _ in POL) + ")", flush=True)
     del plans, ring
     torch.cuda.empty_cache()
