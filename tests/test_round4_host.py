@@ -118,6 +118,7 @@ def test_small_work_gets_the_split_with_more_workgroups():
     assert D(1 << 21, 1, V(1 << 21, 1, 1)) == "col:256+tw col:256+tw autosort:32-tw"
     for lg in (8, 12, 16, 17, 22, 24, 26):
         assert V(1 << lg, 1, 1) == 0
+    assert V(1 << 25, 1, 1) == 33554432 and V(1 << 25, 1, 2) == 0 and D(1 << 25, 1, 33554432) == "col:512+tw col:256+tw col:256"
     assert V(1 << 20, 64, 1) == 0 and V(3 << 19, 1, 1) == 0 and V(1 << 20, 1, 0) == 0
     for lg, b in ((18, 1), (18, 64), (19, 4), (20, 8), (21, 1)):                          # every value it returns is a variant the library accepts
         capi.variant_check(1 << lg, 1, V(1 << lg, 1, b))
