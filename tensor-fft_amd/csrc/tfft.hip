@@ -1126,11 +1126,15 @@ inline bool cache_policy(uint64_t n, uint64_t inner, uint64_t batch) {
   return footprint_policy(n * batch, n <= (1ull << 20) ? 0 : 128);
 }
 
-// Transforms per chunk of a transposed-order plan: about 512 MiB of intermediate (measured, profiles/r4_chunked_transposed.txt:
-// 2^20 x 1024 in chunks of 256 / 128 / 64 / 32 transforms 368 / 375 / 374 / 349 Gsamples/s against 348 for the whole batch; 2^24 x
-// 64 in chunks of 16 / 8 / 4: 322 / 319 / 309 against 311), never chunks so short that a launch has less than 2^26 samples
-inline uint64_t transposed_chunk(uint64_t n, uint64_t batch) {
-  const uint64_t per = std::max<uint64_t>(1, (uint64_t{1} << 27) / n);       // 2^27 samples x 4 B = 512 MiB
+// Transforms per chunk of a transposed-order plan (measured, profiles/r4_chunked_transposed.txt: 2^20 x 1024 in chunks of 256 /
+// 128 / 64 / 32 transforms 368 / 375 / 374 / 349 Gsamples/s against 348 for the whole batch), never chunks so short that a launch
+// has less than 2^26 samples. Transposed OUTPUT: 256 MiB of intermediate, the size of the Infinity Cache: boxes differ (second
+// part of that file): on some 512 MiB is 1-2 % faster at every length, on others it loses the whole gain (2^20 x 1024: 344 with
+// 512 MiB, 373 with 256 MiB, same process), so the size that holds on both is taken. Transposed INPUT: 512 MiB (256 MiB:
+// -3 ... -5 % at 2^16 ... 2^22 on the box where it was tried, +2 % on the other) except 2^24 (4 transforms: 317 against 277).
+inline uint64_t transposed_chunk(uint64_t n, uint64_t batch, bool transposed_in) {
+  const int lg_samples = (transposed_in && n < (uint64_t{1} << 24)) ? 27 : 26;          // x 4 B = 512 / 256 MiB
+  const uint64_t per = std::max<uint64_t>(1, (uint64_t{1} << lg_samples) / n);
   return std::min<uint64_t>(batch, per);
 }
 
@@ -1139,7 +1143,7 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
   // workspace [RE: batch x N | IM: batch x N], then batch * N1 contiguous N2-point transforms from it into `out`, where
   // the N1 rows of one transform sit N2 apart inside the caller's block (grouped addressing).
   const uint64_t n = p->n, n2 = tfft_plan_transposed_n2(n), n1 = n / n2;
-  if (transposed_chunk(n, p->batch) * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "chunk * N1 too large for one launch");
+  if (transposed_chunk(n, p->batch, false) * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "chunk * N1 too large for one launch");
   const int mode = p->scale_mode;
   tfft_plan_opts co = TFFT_PLAN_OPTS_INIT;
   co.in_batch_stride = p->in_stride;
@@ -1153,11 +1157,11 @@ int create_transposed(tfft_plan* p, const tfft_plan_opts* opts, int device_id) {
     return fail(TFFT_ERR_ARG, "tfft_plan_opts.variant " + std::to_string(p->variant) + ": a TFFT_ORDER_TRANSPOSED plan honours only the "
                               "column-pass bits 262144 / 524288 / 536870912 and the single-kernel bits 1 / 2 / 8 / 16 / 1048576");
   co.variant = (p->variant & kColBits) | (n1 == 512 ? 67108864 : 0);
-  if (!(p->variant & (262144 | 536870912)) && footprint_policy(n * transposed_chunk(n, p->batch), 128)) co.variant |= 262144;
+  if (!(p->variant & (262144 | 536870912)) && footprint_policy(n * transposed_chunk(n, p->batch, false), 128)) co.variant |= 262144;
   co.scale = mode == TFFT_SCALE_SEQUENTIAL ? TFFT_SCALE_SEQUENTIAL : TFFT_SCALE_NONE;
   co.fourstep_n = n;
   co.launch_iters = p->launch_iters;
-  p->chunk = transposed_chunk(n, p->batch);
+  p->chunk = transposed_chunk(n, p->batch, false);
   const uint64_t tail = p->batch % p->chunk;
   int rc = create_plan(n1, p->chunk, device_id, &co, InternalOpts{}, &p->sub_col);
   if (rc == TFFT_OK && tail) rc = create_plan(n1, tail, device_id, &co, InternalOpts{}, &p->sub_col_tail);
@@ -1211,7 +1215,7 @@ int create_transposed_in(tfft_plan* p, int device_id) {
   // their fp32 accumulators) into the planar workspace [RE: batch x N | IM: batch x N]; pass 2: one plain radix-N1 column pass
   // along k1 (N2 columns) from it into `out`, whose row p, column q is X[q + N2 p]: natural order.
   const uint64_t n = p->n, n2 = tfft_plan_transposed_n2(n), n1 = n / n2;
-  if (transposed_chunk(n, p->batch) * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "chunk * N1 too large for one launch");
+  if (transposed_chunk(n, p->batch, true) * n1 > 0xffffffffull) return fail(TFFT_ERR_ARG, "chunk * N1 too large for one launch");
   if (p->scale_mode == TFFT_SCALE_ONCE)
     return fail(TFFT_ERR_ARG, "TFFT_SCALE_ONCE is not available with transposed-order input: the plan's last fp32 multiply lies in "
                               "front of its last stage (use TFFT_SCALE_SEQUENTIAL or TFFT_SCALE_NONE)");
@@ -1230,7 +1234,7 @@ int create_transposed_in(tfft_plan* p, int device_id) {
   ri.in_gstride = p->in_stride;            // the rows of one transform sit N2 apart inside the caller's [RE | IM] block
   ri.out_gstride = n;                      // planar workspace: row b at b * N2 either way
   ri.otw_n = n;
-  p->chunk = transposed_chunk(n, p->batch);
+  p->chunk = transposed_chunk(n, p->batch, true);
   const uint64_t tail = p->batch % p->chunk;
   int rc = create_plan(n2, p->chunk * n1, device_id, &ro, ri, &p->sub_row);
   if (rc == TFFT_OK && tail) rc = create_plan(n2, tail * n1, device_id, &ro, ri, &p->sub_row_tail);
