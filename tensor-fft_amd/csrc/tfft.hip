@@ -1302,8 +1302,14 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   int pvariant = opts ? opts->variant : 0;
   if (tw4 && n == 512) pvariant |= 67108864;    // one radix-512 pass
   // the default plan of a caller-facing, natural-order transform that does not fill the chip: the split with more workgroups
-  if (pvariant == 0 && !tw4 && order == TFFT_ORDER_NATURAL && in_order == TFFT_ORDER_NATURAL && io.group_shift == 0 && !io.rows2d &&
-      io.in_seg_len == 0 && io.otw_n == 0)
+  // (caller-facing: not a sub-plan with grouped / segmented addressing or a fused epilogue: those keep what they were tuned with)
+#ifdef TFFT_SUBPLAN_POLICY   // A/B knob: the footprint cache policy for sub-plans too
+  constexpr bool kSubplanPolicy = true;
+#else
+  constexpr bool kSubplanPolicy = false;
+#endif
+  const bool caller_facing = io.group_shift == 0 && !io.rows2d && io.in_seg_len == 0 && io.otw_n == 0;
+  if (pvariant == 0 && !tw4 && order == TFFT_ORDER_NATURAL && in_order == TFFT_ORDER_NATURAL && caller_facing)
     pvariant = small_work_variant(n, inner, batch);
   int rc = check_variant(n, inner, pvariant);
   if (rc) return rc;
@@ -1327,7 +1333,9 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   p->scale_mode = scale_mode;
   // cache policy of the column passes: variant bit 262144 = plain accesses, 536870912 = non-temporal (streaming) accesses,
   // neither = by the plan's footprint (cache_policy)
-  p->plain_acc = (pvariant & 262144) ? true : ((pvariant & 536870912) ? false : cache_policy(n, inner, batch));
+  // (also for the row transforms of a distributed transform, the segmented-input sub-plan: 2^26 over 8 ranks, 2^18 x 32 rows per
+  // rank, local work 65.4 -> 59.6 us on one box, profiles/r4_dist_local_work.txt)
+  p->plain_acc = (pvariant & 262144) ? true : ((pvariant & 536870912) ? false : ((caller_facing || io.in_seg_len != 0 || kSubplanPolicy) && cache_policy(n, inner, batch)));
   p->tw4_modulus = tw4;
   p->tw4_col0 = opts ? opts->fourstep_col0 : 0;
   p->in_map = k4096::Addr{in_stride, io.group_shift ? io.in_gstride : in_stride, io.group_shift, (1u << io.group_shift) - 1u};

@@ -14,6 +14,9 @@ g.build()
 import tensor_fft_amd as tf
 from tensor_fft_amd import capi
 
+if os.environ.get("TFFT_AB_LIB"):            # another build of the library (tools/build_ab.py), for same-box comparisons
+    capi._LIB_NAME = os.path.abspath(os.environ["TFFT_AB_LIB"])
+    capi._lib = None                            # (g.build() above has already loaded the default build)
 what = sys.argv[1] if len(sys.argv) > 1 else "emu"
 
 
@@ -114,7 +117,10 @@ if what == "legacy":
         legacy(lg, w)
         emulate_time_only = True
 elif what == "emu":
-    for lg, w in ((20, 1), (20, 2), (21, 4), (24, 4), (24, 2), (25, 4), (26, 2), (26, 8), (16, 2)):
+    cases = ((20, 1), (20, 2), (21, 4), (24, 4), (24, 2), (25, 4), (26, 2), (26, 8), (16, 2))
+    if len(sys.argv) > 2:                    # python tools/try_dist.py emu 26:8 25:4 ...
+        cases = tuple(tuple(int(v) for v in a.split(":")) for a in sys.argv[2:])
+    for lg, w in cases:
         emulate(lg, w)
 elif what == "self":
     from tensor_fft_amd.distributed import DistributedFFT1D, HipEngine
