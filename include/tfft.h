@@ -215,7 +215,7 @@ int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch);
 /* Host only. The planner bits tfft_plan_create gives a NATURAL-order plan whose caller left `variant` at 0: 0 when the work
  * (n * batch samples) fills the chip - the splits behind variant 0 were measured at 2^30 samples per launch - and otherwise
  * the bits of the split with more, smaller workgroups (a single 2^20-point transform is 16 workgroups of the radix-1024 kernel
- * on 256 CUs: 40 us; as 256 x 256 x 16 it takes 24 us). 2^18 ... 2^21 and a single 2^25 only; measured limits:
+ * on 256 CUs: 40 us; as 256 x 256 x 16 it takes 24 us). 2^17 ... 2^21, two 2^24 and a single 2^25 only; measured limits:
  * profiles/r4_small_batch_scan.txt.
  * tfft_plan_describe(n, inner, tfft_plan_default_variant(n, inner, batch), ...) is the decomposition such a plan gets. A caller
  * that names any variant bit itself gets exactly that variant. */

@@ -112,15 +112,17 @@ def test_small_work_gets_the_split_with_more_workgroups():
     assert D(1 << 20, 1, V(1 << 20, 1, 1)) == "col:256+tw col:256+tw autosort:16-tw" and D(1 << 20, 1, V(1 << 20, 1, 1024)) == "col:1024+tw col:1024"
     assert V(1 << 19, 1, 4) == 33554432 and V(1 << 19, 1, 8) == 0
     assert D(1 << 19, 1, V(1 << 19, 1, 1)) == "col:256+tw col:256+tw autosort:8-tw"
-    assert V(1 << 18, 1, 16) == 268435456 and V(1 << 18, 1, 32) == 524288 and V(1 << 18, 1, 64) == 524288 and V(1 << 18, 1, 128) == 0
+    assert V(1 << 18, 1, 16) == 268435456 and V(1 << 18, 1, 32) == 524288 and V(1 << 18, 1, 64) == 524288 and V(1 << 18, 1, 128) == 524288 and V(1 << 18, 1, 256) == 0
     assert D(1 << 18, 1, V(1 << 18, 1, 1)) == "col:512+tw col:512"            # same split, the other radix-512 kernel
     assert V(1 << 21, 1, 1) == 8388608 and V(1 << 21, 1, 2) == 0
     assert D(1 << 21, 1, V(1 << 21, 1, 1)) == "col:256+tw col:256+tw autosort:32-tw"
     for lg in (8, 12, 16, 17, 22, 24, 26):
         assert V(1 << lg, 1, 1) == 0
+    assert V(1 << 17, 1, 32) == 0 and V(1 << 17, 1, 64) == 524288 and V(1 << 17, 1, 256) == 524288 and V(1 << 17, 1, 512) == 0
+    assert V(1 << 24, 1, 2) == 33554432 and V(1 << 24, 1, 3) == 0 and D(1 << 24, 1, 33554432) == "col:256+tw col:256+tw col:256"
     assert V(1 << 25, 1, 1) == 33554432 and V(1 << 25, 1, 2) == 0 and D(1 << 25, 1, 33554432) == "col:512+tw col:256+tw col:256"
     assert V(1 << 20, 64, 1) == 0 and V(3 << 19, 1, 1) == 0 and V(1 << 20, 1, 0) == 0
-    for lg, b in ((18, 1), (18, 64), (19, 4), (20, 8), (21, 1)):                          # every value it returns is a variant the library accepts
+    for lg, b in ((17, 64), (18, 1), (18, 64), (19, 4), (20, 8), (21, 1), (24, 2), (25, 1)):                          # every value it returns is a variant the library accepts
         capi.variant_check(1 << lg, 1, V(1 << lg, 1, b))
 
 
