@@ -424,12 +424,6 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < kLdsTable / 16; i += G::kThreadsW)
-    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(a.tables + kOffG)[i];
-  const h8 f_re = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32);
-  const h8 f_im = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32 + 16);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
   uint8_t* const img = lds + kLdsTable;
   const uint32_t img_off = __builtin_amdgcn_readfirstlane(
@@ -455,12 +449,10 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
   // (adjacent column blocks run on different CUs at the same time: measured 1-2 % faster than giving each
   // workgroup a contiguous range of blocks)
   Rotor rot(blockIdx.x, gridDim.x);                                      // (block order: k4096::Rotor)
-  for (uint32_t blk = rot.item(); blk < total; rot.advance(), blk = rot.item()) {
-    const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;        // first flattened column of the block
-    const uint64_t gcw = gc0 + 16 * wave;                              // ... of this wave
-    const uint64_t bidx = gcw >> pshift;                               // this wave's batch entry
-    const uint64_t mb = gc0 & (a.pitch - 1);                           // first column of the block (pitch >= 16 W)
-    const uint64_t m0 = gcw & (a.pitch - 1);                           // first column of this wave
+  // copy-in of block blk_in (LDS-DMA, asynchronous): issued for the first block AHEAD of the table fetch below, for every further
+  // block at the end of the iteration before it (the loop's increment expression; the image is free by then, barrier D)
+  auto copy_in = [&](uint32_t blk_in) {
+    const uint64_t gc0 = static_cast<uint64_t>(blk_in) * G::kCols;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t sr = 32 * wave + 4 * i + (lane >> 4);
@@ -500,6 +492,30 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
             : "v"(gr), "v"(gi), "s"(d0), "s"(d1)
             : "memory");
     }
+  };
+  const uint32_t blk0 = rot.item();
+  if (blk0 < total) copy_in(blk0);
+  // constant tables (G operands to LDS, F operands to registers) BEHIND the first block's loads: a workgroup with one or two blocks
+  // (a plan that does not fill the chip; the generations launch shape) would otherwise spend a whole memory latency on its tables
+  // before its first data load is issued (2^16 x 1: 16.0 -> 13.6 us, x 64: 25.7 -> 20.7 us, profiles/r4_table_prologue.txt)
+  for (int i = tid; i < kLdsTable / 16; i += G::kThreadsW)
+    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(a.tables + kOffG)[i];
+  const h8 f_re = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32);
+  const h8 f_im = *reinterpret_cast<const h8*>(a.tables + kOffF1n + lane * 32 + 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  auto next_block = [&]() {
+    rot.advance();
+    const uint32_t nb = rot.item();
+    if (nb < total) copy_in(nb);
+    return nb;
+  };
+  for (uint32_t blk = blk0; blk < total; blk = next_block()) {
+    const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;        // first flattened column of the block
+    const uint64_t gcw = gc0 + 16 * wave;                              // ... of this wave
+    const uint64_t bidx = gcw >> pshift;                               // this wave's batch entry
+    const uint64_t mb = gc0 & (a.pitch - 1);                           // first column of the block (pitch >= 16 W)
+    const uint64_t m0 = gcw & (a.pitch - 1);                           // first column of this wave
     // twiddle set-up (table look-ups fly with the copy-in), exactly as in the per-wave kernel
     const uint64_t rest = m0 >> a.ns_f_shift;
     const uint64_t kprev_f0 = m0 - (rest << a.ns_f_shift);
