@@ -1103,9 +1103,9 @@ inline bool footprint_policy(uint64_t samples, uint64_t lo_mib) {
 //   2^18: the single-round radix-512 kernel for the final pass (64-column tiles)    x 1: 26.4 -> 19.7 us, x 16: 32.5 -> 28.4 us
 //         then, to 2^25 samples, 4-wave workgroups                                   x 32: 38.5 -> 33.3 us, x 64: 57.9 -> 52.1 us, x 128: 116.6 -> 111.7 us
 //   2^17: 4-wave workgroups from 2^23 to 2^25 samples                                x 64: 30.2 -> 27.9 us, x 256: 114.8 -> 111.3 us
-//   2^19: 256 x 256 x 8 instead of 512 x 1024                                        x 1: 27.4 -> 22.0 us, x 4: 31.6 -> 29.2 us
+//   2^19: 256 x 256 x 8 instead of 512 x 1024, to 2^22 samples                       x 1: 27.4 -> 22.0 us, x 4: 31.6 -> 29.2 us, x 8: 35.2 -> 32.9 us
 //   2^20: 256 x 256 x 16 instead of 1024 x 1024                                      x 1: 40.1 -> 24.1 us, x 4: 48.8 -> 38.1 us
-//   2^21: 256 x 256 x 32 instead of 512 x 512 x 8                                    x 1: 35.1 -> 30.4 us
+//   2^21: 256 x 256 x 32 instead of 512 x 512 x 8, to 2^22 samples                   x 1: 35.1 -> 30.4 us, x 2: 35.8 -> 32.9 us
 //   2^25: 512 x 256 x 256 instead of 1024 x 1024 x 32                                x 1: 198.5 -> 180.7 us (x 2: +1.5 %, not taken)
 //   2^24: 256 x 256 x 256 for exactly two transforms                                 x 2: 184.4 -> 172.7 us (three scans; x 1, x 4: the default wins)
 // Only variant 0 is touched: a caller (or tuner file) that names any bit gets exactly what it names.
@@ -1119,9 +1119,9 @@ inline int small_work_variant(uint64_t n, uint64_t inner, uint64_t batch) {
   switch (lg) {
     case 17: return (work >= (1ull << 23) && work <= (1ull << 25)) ? 524288 : 0;
     case 18: return work <= (1ull << 22) ? 268435456 : (work <= (1ull << 25) ? 524288 : 0);
-    case 19: return work <= (1ull << 21) ? 33554432 : 0;
+    case 19: return work <= (1ull << 22) ? 33554432 : 0;
     case 20: return work <= (1ull << 23) ? 33554432 : 0;
-    default: return work <= (1ull << 21) ? 8388608 : 0;
+    default: return work <= (1ull << 22) ? 8388608 : 0;
   }
 }
 

@@ -430,7 +430,7 @@ def test_cache_policy_changes_the_time_never_the_result(tf, lg, batch, order):
     assert not torch.isnan(outs[0].view(torch.float16)).any()
 
 
-@pytest.mark.parametrize("lg,batch", [(18, 1), (18, 16), (18, 32), (18, 64), (18, 128), (19, 1), (19, 4), (19, 8), (20, 1), (20, 8), (20, 16), (21, 1), (21, 2), (25, 1), (17, 64), (17, 256), (24, 2)])
+@pytest.mark.parametrize("lg,batch", [(18, 1), (18, 16), (18, 32), (18, 64), (18, 128), (19, 1), (19, 4), (19, 8), (19, 16), (20, 1), (20, 8), (20, 16), (21, 1), (21, 2), (21, 4), (25, 1), (17, 64), (17, 256), (24, 2)])
 def test_small_work_default_split_against_the_oracle_and_the_large_batch_split(tf, orc, lg, batch):
     """A variant-0 plan that does not fill the chip takes the split with more workgroups (tfft_plan_default_variant). Either split
     must be within the stated tolerance of the fp64 oracle, and the default plan must BE the variant it reports."""

@@ -110,11 +110,11 @@ def test_small_work_gets_the_split_with_more_workgroups():
     V, D = tf.plan_default_variant, tf.plan_describe
     assert V(1 << 20, 1, 1) == 33554432 and V(1 << 20, 1, 8) == 33554432 and V(1 << 20, 1, 16) == 0 and V(1 << 20, 1, 1024) == 0
     assert D(1 << 20, 1, V(1 << 20, 1, 1)) == "col:256+tw col:256+tw autosort:16-tw" and D(1 << 20, 1, V(1 << 20, 1, 1024)) == "col:1024+tw col:1024"
-    assert V(1 << 19, 1, 4) == 33554432 and V(1 << 19, 1, 8) == 0
+    assert V(1 << 19, 1, 8) == 33554432 and V(1 << 19, 1, 16) == 0
     assert D(1 << 19, 1, V(1 << 19, 1, 1)) == "col:256+tw col:256+tw autosort:8-tw"
     assert V(1 << 18, 1, 16) == 268435456 and V(1 << 18, 1, 32) == 524288 and V(1 << 18, 1, 64) == 524288 and V(1 << 18, 1, 128) == 524288 and V(1 << 18, 1, 256) == 0
     assert D(1 << 18, 1, V(1 << 18, 1, 1)) == "col:512+tw col:512"            # same split, the other radix-512 kernel
-    assert V(1 << 21, 1, 1) == 8388608 and V(1 << 21, 1, 2) == 0
+    assert V(1 << 21, 1, 2) == 8388608 and V(1 << 21, 1, 4) == 0
     assert D(1 << 21, 1, V(1 << 21, 1, 1)) == "col:256+tw col:256+tw autosort:32-tw"
     for lg in (8, 12, 16, 17, 22, 24, 26):
         assert V(1 << lg, 1, 1) == 0
