@@ -363,6 +363,19 @@ inline uint32_t gens_grid(uint64_t blocks, uint32_t capacity, uint32_t launch_it
 }
 constexpr uint32_t kGensStatic = 1, kGensCol8 = 2, kGensCol4 = 8;    // per kernel family, see above
 
+// The radix-256 workgroup kernel since its tables are fetched behind its first block's copy-in (colfft.hpp, end of round 4): a
+// workgroup's start-up is cheap enough for about FOUR rounds per workgroup to be the best shape, however many generations that
+// makes (profiles/r4_gens_after_prologue.txt, one process: 2^16 x 4096 345 -> 369 Gsamples/s, 2^16 x 16384 357 -> 365, 256-point
+// transforms along a strided axis +1 ... +1.5 %; one or two rounds per workgroup lose 1 ... 9 %). Whole multiples of the resident
+// capacity, as above.
+inline uint32_t rounds_grid(uint64_t blocks, uint32_t capacity, uint32_t launch_iters) {
+  if (launch_iters) return pick_grid(blocks, static_cast<int>(capacity), plan_iters(launch_iters, 1000000u));
+  constexpr uint64_t kRounds = 4, kMaxGens = 64;
+  const uint64_t gens = std::min<uint64_t>(kMaxGens, blocks / (static_cast<uint64_t>(capacity) * kRounds));
+  if (gens >= 2) return static_cast<uint32_t>(capacity * gens);
+  return static_cast<uint32_t>(std::min<uint64_t>(blocks, capacity));
+}
+
 template <int V>
 int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                    k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
@@ -555,7 +568,7 @@ int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
   }
 #endif
   const uint32_t grid = iters_dflt != 1000000u ? pick_grid(blocks, p->num_cus * (8 / W), plan_iters(p->launch_iters, iters_dflt))
-                                               : gens_grid(blocks, static_cast<uint32_t>(p->num_cus * (8 / W)), p->launch_iters, W == 4 ? kGensCol4 : kGensCol8);
+                                               : rounds_grid(blocks, static_cast<uint32_t>(p->num_cus * (8 / W)), p->launch_iters);
   TFFT_LAUNCH((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid), dim3(G::kThreadsW), G::kLds, s, a);
   return TFFT_OK;
 }
