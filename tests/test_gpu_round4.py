@@ -463,3 +463,29 @@ def test_small_work_default_split_against_the_oracle_and_the_large_batch_split(t
             got = outs[name][b, 0].astype(np.float64) + 1j * outs[name][b, 1].astype(np.float64)
             rel = np.linalg.norm(got - exact) / np.linalg.norm(exact)
             assert rel <= 1.5e-3, (name, lg, batch, b, rel)
+
+
+@pytest.mark.parametrize("n,inner,batch", [(1 << 16, 1, 129), (1 << 16, 1, 513), (1 << 16, 1, 2049), (1 << 16, 1, 4100),
+                                           (256, 64, 8191), (256, 4096, 131), (1 << 17, 1, 1027)])
+def test_rounds_per_workgroup_launch_shape_at_ragged_block_counts(tf, n, inner, batch):
+    """The radix-256 workgroup kernel is launched with about four rounds per workgroup in whole multiples of the resident
+    capacity (tfft.hip rounds_grid): block counts just off those multiples, against the static partition (launch_iters =
+    persistent) and one round per workgroup, bit for bit."""
+    import torch
+
+    nf = n * inner
+    x = torch.empty(batch * 2 * nf, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x, x[nf:], nf, batch)
+    outs = []
+    for it in (0, 65535, 1):
+        plan = tf.TfftPlan(n, batch, 0, inner=inner, preserve_input=True, launch_iters=it)
+        ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+        if plan.workspace_bytes:
+            plan.set_workspace(ws)
+        y = torch.full_like(x, float("nan"))
+        plan.exec(x, x[nf:], y, y[nf:])
+        torch.cuda.synchronize()
+        outs.append(y.view(torch.int16))
+        plan.close()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert not torch.isnan(outs[0].view(torch.float16)).any()
