@@ -361,7 +361,7 @@ inline uint32_t gens_grid(uint64_t blocks, uint32_t capacity, uint32_t launch_it
   if (gens > 1 && blocks >= static_cast<uint64_t>(capacity) * gens * kMinRounds) return capacity * gens;
   return static_cast<uint32_t>(std::min<uint64_t>(blocks, capacity));
 }
-constexpr uint32_t kGensStatic = 1, kGensCol8 = 2, kGensCol4 = 8;    // per kernel family, see above
+constexpr uint32_t kGensStatic = 1, kGensCol8 = 2;    // per kernel family, see above (the radix-256 workgroup kernel: rounds_grid below)
 
 // The radix-256 workgroup kernel since its tables are fetched behind its first block's copy-in (colfft.hpp, end of round 4): a
 // workgroup's start-up is cheap enough for about FOUR rounds per workgroup to be the best shape, however many generations that
