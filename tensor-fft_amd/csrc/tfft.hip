@@ -1683,6 +1683,9 @@ int tfft_plan2d_create(uint64_t rows, uint64_t cols, uint64_t batch, int device_
 #ifdef TFFT_2D_COL_VARIANT     // A/B knob: cache-policy bits (262144 / 536870912) for the column pass
       co.variant |= TFFT_2D_COL_VARIANT;
 #endif
+#ifdef TFFT_2D_COL_ITERS       // A/B knob: rounds per workgroup of the column pass (default: the static partition for a chunk)
+      co.launch_iters = TFFT_2D_COL_ITERS;
+#endif
 #ifdef TFFT_2D_CHUNK           // A/B knob
       constexpr uint64_t kChunkImages = TFFT_2D_CHUNK;
 #else
