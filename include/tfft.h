@@ -391,6 +391,12 @@ int tfft_synth_uniform(void* re, void* im, uint64_t n, uint64_t batch, uint64_t 
 /* Name of the dominant kernel of this plan (for profiler summaries) and the
  * algorithmic HBM bytes / MFMA flops of one tfft_exec (SURVEY 8d accounting). */
 const char* tfft_plan_kernel_name(const tfft_plan* plan);
+
+/* Host only: the column-pass kernel instantiations this library ships, one demangled name per line ("colfft::colfft512_wg_kernel<1, 2,
+ * false, true>"), as the library's dispatch table holds them (tfft.hip, TFFT_COL_* lists: a kernel variant is a row of that table,
+ * and the launch path can reach no instantiation outside it). Returns the number of rows, or TFFT_ERR_ARG when `bytes` is too
+ * small. tests/test_isa_lint.py compares the list with the symbols of the gfx950 code object. No counterpart in the reference. */
+int tfft_kernel_list(char* buf, size_t bytes);
 double tfft_plan_algorithmic_bytes(const tfft_plan* plan);
 double tfft_plan_mfma_flops(const tfft_plan* plan);
 

@@ -25,7 +25,7 @@ SYMBOLS = [
     "tfft_dist_plan_destroy", "tfft_dist_plan_geometry", "tfft_dist_plan_buffers", "tfft_dist_plan_set_buffers",
     "tfft_dist_exec_pre", "tfft_dist_exec_exchange", "tfft_dist_exec_post", "tfft_dist_exec",
     "tfft_copy_h2d", "tfft_copy_d2h", "tfft_plan_prepare", "tfft_plan_opts_init", "tfft_plan_opts_known_size",
-    "tfft_dist_rccl_version", "tfft_dist_comm_info",
+    "tfft_dist_rccl_version", "tfft_dist_comm_info", "tfft_kernel_list",
 ]
 
 LAUNCH_PERSISTENT = 65535                                     # tfft_plan_opts.launch_iters
@@ -106,8 +106,11 @@ DIST_SELF_VIA_COMM, DIST_CALLER_BUFFERS = 1, 2          # tfft_dist_plan_create 
 
 def lib_path():
     """libtfft.so. Only the measurement drivers under tools/ (which set TFFT_DEBUG_VARIANTS=1 and TFFT_USE_DEBUG_LIB=1
-    before the first load) get libtfft_debug.so, the -DTFFT_DEBUG_KERNELS build with the timing-only kernels."""
-    return os.path.join(_HERE, "libtfft_debug.so" if _debug_requested() else _LIB_NAME)
+    before the first load) get build/libtfft_debug.so, the -DTFFT_DEBUG_KERNELS build with the timing-only kernels; the package
+    directory holds nothing but the shipped library."""
+    if _debug_requested():
+        return os.path.join(os.path.dirname(_HERE), "build", "libtfft_debug.so")
+    return os.path.join(_HERE, _LIB_NAME)
 
 
 _lib = None
@@ -257,6 +260,20 @@ def plan_describe(n, inner=1, variant=0):
     buf = ctypes.create_string_buffer(256)
     _check(load_library().tfft_plan_describe(int(n), int(inner), int(variant), buf, len(buf)))
     return buf.value.decode()
+
+
+def kernel_list():
+    """tfft_kernel_list: the column-kernel instantiations of the library's dispatch table (demangled names). Host only."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    L = load_library()
+    L.tfft_kernel_list.restype = ctypes.c_int
+    L.tfft_kernel_list.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    rc = L.tfft_kernel_list(buf, len(buf))
+    if rc < 0:
+        raise TfftError(rc, last_error())
+    names = buf.value.decode().split("\n")[:-1]
+    assert len(names) == rc
+    return names
 
 
 def variant_check(n, inner=1, variant=0):

@@ -117,6 +117,20 @@ struct Args {
 // twiddle forms of a column pass: none, the next autosort pass's input twiddles, the four-step twiddle
 enum : int { kTwNone = 0, kTwNext = 1, kTwFourStep = 2 };
 
+// Measurement build only (tools/exp_lat_phases.py): wall clock (100 MHz) of workgroup i at phase ph into wg_times[ph * 8192 + i],
+// the shader clock (s_memtime) into wg_times[(8 + ph) * 8192 + i]. Nothing in the shipped library.
+#ifdef TFFT_DEBUG_KERNELS
+#define TFFT_WG_STAMP(a, ph)                                                                   \
+  do {                                                                                         \
+    if ((a).wg_times && threadIdx.x == 0 && blockIdx.x < 8192) {                               \
+      (a).wg_times[(ph) * 8192 + blockIdx.x] = wall_clock64();                                 \
+      (a).wg_times[(8 + (ph)) * 8192 + blockIdx.x] = __builtin_amdgcn_s_memtime();             \
+    }                                                                                          \
+  } while (0)
+#else
+#define TFFT_WG_STAMP(a, ph) do { } while (0)
+#endif
+
 // Store policy of a column pass (round 4). A four-step pass (kTwFourStep) writes the INTERMEDIATE of a transposed-order plan, which
 // the contiguous row pass of the same chunk of the batch reads right back (tfft.hip launch_chain runs those plans chunk by
 // chunk): plain stores, so that the lines stay in the 256-MiB Infinity Cache: 2^20 x 1024 in transposed output order 341-348 ->
@@ -425,6 +439,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  TFFT_WG_STAMP(a, 0);
   uint8_t* const img = lds + kLdsTable;
   const uint32_t img_off = __builtin_amdgcn_readfirstlane(
       static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)img)));
@@ -550,8 +565,10 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         base[r] = cpx{__builtin_amdgcn_cosf(fb) * a.tw_scale, -__builtin_amdgcn_sinf(fb) * a.tw_scale};
       }
     }
+    TFFT_WG_STAMP(a, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // A: the whole block is in LDS
+    TFFT_WG_STAMP(a, 2);
 
 #ifdef TFFT_DEBUG_KERNELS
     if (MODE == kColsInRegs && a.copy_only) {
@@ -603,6 +620,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // B: every wave has read its slab; the image may be overwritten
+    TFFT_WG_STAMP(a, 3);
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
@@ -700,6 +718,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
         }
       }
     }
+    if (MODE == kColsOnLanes) TFFT_WG_STAMP(a, 4);
     if (MODE == kColsOnLanes && STG) {
       // the slice is private to this wave (it is also exactly the LDS range of this wave's next copy-in): no barrier
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -723,6 +742,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
     if (MODE == kColsInRegs) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();          // C: the output image is complete
+      TFFT_WG_STAMP(a, 4);
       const uint64_t restb = mb >> a.ns_f_shift;                 // the block's columns share it (ns_f % (16 W) == 0)
       const uint64_t obase = ((restb << 8) << a.ns_f_shift) + (mb - (restb << a.ns_f_shift));
 #pragma unroll
@@ -749,7 +769,12 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();          // D: read out; the next block's copy-in may overwrite the image
     }
+    TFFT_WG_STAMP(a, 5);
   }
+#ifdef TFFT_DEBUG_KERNELS
+  if (a.wg_times) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (measurement build: exit stamp behind the stores)
+#endif
+  TFFT_WG_STAMP(a, 6);
 }
 
 // ---------------------------------------------------------------------------

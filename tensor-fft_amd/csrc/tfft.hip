@@ -541,63 +541,138 @@ struct Planes {
   uint64_t stride;
 };
 
-template <int MODE, int TW, bool STAGE, bool LUT>
-int launch_col_t(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
-  const uint32_t blocks_needed = (a.tasks + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock;
-  static const uint32_t iters_dflt = env_iters("TFFT_COL_ITERS", 1000000);
-  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
-  TFFT_LAUNCH((colfft::colfft256_kernel<MODE, TW, STAGE, LUT>), dim3(grid), dim3(k4096::kThreads), colfft::kLdsBytes, s, a);
+// ---------------------------------------------------------------------------------------------------------------------
+// The column kernels this library ships: ONE list per kernel family. The dispatch table below, the names tfft_kernel_list()
+// reports and (through tests/test_isa_lint.py, which compares that list with the symbols of the gfx950 code object) the set of
+// instantiations in libtfft.so all come from these lists: a further variant is a further row, not a further branch of a ladder.
+// Arguments are written the way the demangler prints them (bools as false / true), because the row's name is built from them.
+// ---------------------------------------------------------------------------------------------------------------------
+// colfft256_kernel<MODE, TW, STAGE, LUT>: per-wave radix-256 pass (16-column tiles)
+#define TFFT_COL_WAVE(X)                                                                                     \
+  X(0, 1, false, false) X(0, 1, false, true) X(0, 1, true, false) X(0, 1, true, true) X(0, 0, false, false)  \
+  X(0, 0, true, false) X(1, 1, false, false) X(1, 1, false, true) X(1, 1, true, false) X(1, 1, true, true)   \
+  X(1, 0, false, false) X(1, 0, true, false)
+// colfft256_wg_kernel<MODE, TW, NT, W, STG>: workgroup-cooperative radix-256 pass, W = 4 / 8 waves; STG only with MODE 0
+#define TFFT_COL_WG256_W(X, W)                                                                               \
+  X(0, 0, false, W, false) X(0, 0, false, W, true) X(0, 0, true, W, false) X(0, 0, true, W, true)            \
+  X(0, 1, false, W, false) X(0, 1, false, W, true) X(0, 1, true, W, false) X(0, 1, true, W, true)            \
+  X(1, 0, false, W, false) X(1, 0, true, W, false) X(1, 1, false, W, false) X(1, 1, true, W, false)          \
+  X(1, 2, false, W, false) X(1, 2, true, W, false)
+#define TFFT_COL_WG256(X) TFFT_COL_WG256_W(X, 4) TFFT_COL_WG256_W(X, 8)
+// colfft512_wg_kernel<MODE, TW, SC, PLAIN> and colfft1024_wg_kernel<MODE, TW, SC, PLAIN>; SC = "scale once" read-out of a final pass
+#define TFFT_COL_512(X)                                                                                      \
+  X(0, 0, false, false) X(0, 0, false, true) X(0, 1, false, false) X(0, 1, false, true) X(1, 0, false, false) \
+  X(1, 0, false, true) X(1, 0, true, false) X(1, 1, false, false) X(1, 1, false, true) X(1, 2, false, false)  \
+  X(1, 2, false, true)
+#define TFFT_COL_1024(X)                                                                                     \
+  X(0, 0, false, false) X(0, 0, false, true) X(0, 1, false, false) X(0, 1, false, true) X(1, 0, false, false) \
+  X(1, 0, false, true) X(1, 0, true, false) X(1, 1, false, false) X(1, 1, false, true)
+// colfft512r_wg_kernel<W, SC, PF, PLAIN>: two-round radix-512 pass (PF = next tile prefetched through registers: the 8-wave form)
+#define TFFT_COL_512R(X)                                                                                     \
+  X(8, false, true, false) X(8, false, true, true) X(8, true, true, false) X(4, false, false, false)         \
+  X(4, false, false, true) X(4, true, false, false)
+
+enum : uint32_t { kFamWave = 1, kFamWg256 = 2, kFam512 = 3, kFam512R = 4, kFam1024 = 5 };
+using ColKernel = void (*)(colfft::Args);
+struct ColRow {
+  uint32_t key;
+  ColKernel fn;
+  uint32_t threads, lds;
+  const char* name;
+};
+constexpr uint32_t col_key(uint32_t fam, int a, int b, int c, int d, int e = 0) {
+  return (fam << 20) | (static_cast<uint32_t>(a) << 16) | (static_cast<uint32_t>(b) << 12) | (static_cast<uint32_t>(c) << 8) |
+         (static_cast<uint32_t>(d) << 4) | static_cast<uint32_t>(e);
+}
+const ColRow kColTable[] = {
+#define X(MODE, TW, STAGE, LUT)                                                                                      \
+  {col_key(kFamWave, MODE, TW, STAGE, LUT), colfft::colfft256_kernel<MODE, TW, STAGE, LUT>, k4096::kThreads, colfft::kLdsBytes, \
+   "colfft::colfft256_kernel<" #MODE ", " #TW ", " #STAGE ", " #LUT ">"},
+    TFFT_COL_WAVE(X)
+#undef X
+#define X(MODE, TW, NT, W, STG)                                                                                      \
+  {col_key(kFamWg256, MODE, TW, NT, W, STG), colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>, 64 * W, colfft::WgGeom<W>::kLds,   \
+   "colfft::colfft256_wg_kernel<" #MODE ", " #TW ", " #NT ", " #W ", " #STG ">"},
+    TFFT_COL_WG256(X)
+#undef X
+#define X(MODE, TW, SC, PLAIN)                                                                                       \
+  {col_key(kFam512, MODE, TW, SC, PLAIN), colfft::colfft512_wg_kernel<MODE, TW, SC, PLAIN>, k4096::kThreads, colfft::kWg512LdsBytes, \
+   "colfft::colfft512_wg_kernel<" #MODE ", " #TW ", " #SC ", " #PLAIN ">"},
+    TFFT_COL_512(X)
+#undef X
+#define X(MODE, TW, SC, PLAIN)                                                                                       \
+  {col_key(kFam1024, MODE, TW, SC, PLAIN), colfft::colfft1024_wg_kernel<MODE, TW, SC, PLAIN>, k4096::kThreads, colfft::kWg1024LdsBytes, \
+   "colfft::colfft1024_wg_kernel<" #MODE ", " #TW ", " #SC ", " #PLAIN ">"},
+    TFFT_COL_1024(X)
+#undef X
+#define X(W, SC, PF, PLAIN)                                                                                          \
+  {col_key(kFam512R, W, SC, PF, PLAIN), colfft::colfft512r_wg_kernel<W, SC, PF, PLAIN>, 64 * W, colfft::wg512r_lds_bytes<W>(),  \
+   "colfft::colfft512r_wg_kernel<" #W ", " #SC ", " #PF ", " #PLAIN ">"},
+    TFFT_COL_512R(X)
+#undef X
+};
+constexpr size_t kColRows = sizeof(kColTable) / sizeof(kColTable[0]);
+
+inline const ColRow* col_row(uint32_t key) {
+  for (const ColRow& r : kColTable)
+    if (r.key == key) return &r;
+  return nullptr;
+}
+
+// the one launch site of every column kernel (lds_bytes = 0: the row's own LDS size)
+int launch_col_row(const tfft_plan* p, uint32_t key, uint32_t grid, const colfft::Args& a, hipStream_t s, uint32_t lds_bytes = 0) {
+  const ColRow* const r = col_row(key);
+  if (!r) return fail(TFFT_ERR_ARG, "internal error: column kernel " + std::to_string(key) + " is not in the dispatch table");
+  const uint32_t lds = lds_bytes ? lds_bytes : r->lds;
+  const int rc = lds_opt_in(reinterpret_cast<const void*>(r->fn), p->device, static_cast<int>(lds));
+  if (rc) return rc;
+  if (!g_prepare) hipLaunchKernelGGL(r->fn, dim3(grid), dim3(r->threads), lds, s, a);
   return TFFT_OK;
 }
 
-template <int MODE, int TW, bool NT, int W, bool STG = false>
-int launch_col_wg(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
-  using G = colfft::WgGeom<W>;
-  const uint64_t blocks = (a.tasks / a.groups) * a.pitch / G::kCols;
+// per-wave kernel: 8 waves per workgroup, one 16-column tile per wave and round
+int launch_col_wave(const tfft_plan* p, int mode, int tw, bool stage, bool lut, const colfft::Args& a, hipStream_t s) {
+  const uint32_t blocks_needed = (a.tasks + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock;
+  static const uint32_t iters_dflt = env_iters("TFFT_COL_ITERS", 1000000);
+  const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
+  return launch_col_row(p, col_key(kFamWave, mode, tw, stage, tw == colfft::kTwNone ? false : lut), grid, a, s);
+}
+
+// workgroup-cooperative radix-256 kernel, W = 4 or 8 waves
+int launch_col_wg(const tfft_plan* p, int mode, int tw, int w, const colfft::Args& a, hipStream_t s) {
+  const uint32_t cols = 16u * static_cast<uint32_t>(w);
+  const uint64_t blocks = (a.tasks / a.groups) * a.pitch / cols;
+  // non-temporal copy-in and row stores unless the plan's cache policy says plain (tfft_plan_cache_policy, variant bit 262144);
+  // columns-on-lanes form: staged full-row stores (variant bit 1048576: direct 16-byte pieces)
+  const bool nt = !p->plain_acc;
+  const bool stg = mode == colfft::kColsOnLanes && !(p->variant & 1048576);
+  const uint32_t key = col_key(kFamWg256, mode, tw, nt, w, stg);
   static const uint32_t iters_dflt = env_iters("TFFT_COLWG_ITERS", 1000000);
 #ifdef TFFT_DEBUG_KERNELS
   // experiment knob: TFFT_WG4_ONE_PER_CU=1 launches the 4-wave workgroups with so much dynamic LDS (96 KiB) that only ONE fits a CU:
   // the same kernel at one wave per SIMD instead of two (what a radix-1024 pass with 128-column tiles would have to run at).
   // Round 4, against the static partition: +3 ... +10 % on one box; against today's default (8 generations of two per CU), as a
   // variant bit in one process: -3 ... -20 % (profiles/r4_one_wave_per_simd.txt): not a launch shape worth keeping.
-  static const bool one_per_cu = W == 4 && env_iters("TFFT_WG4_ONE_PER_CU", 0) != 0;
-  if (one_per_cu) {
-    const uint32_t grid1 = gens_grid(blocks, static_cast<uint32_t>(p->num_cus), p->launch_iters, env_iters("TFFT_GENS", 1));
-    TFFT_LAUNCH((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid1), dim3(G::kThreadsW), 96 * 1024, s, a);
-    return TFFT_OK;
-  }
+  static const bool one_per_cu = env_iters("TFFT_WG4_ONE_PER_CU", 0) != 0;
+  if (one_per_cu && w == 4)
+    return launch_col_row(p, key, gens_grid(blocks, static_cast<uint32_t>(p->num_cus), p->launch_iters, env_iters("TFFT_GENS", 1)), a, s, 96 * 1024);
 #endif
-  const uint32_t grid = iters_dflt != 1000000u ? pick_grid(blocks, p->num_cus * (8 / W), plan_iters(p->launch_iters, iters_dflt))
-                                               : rounds_grid(blocks, static_cast<uint32_t>(p->num_cus * (8 / W)), p->launch_iters);
-  TFFT_LAUNCH((colfft::colfft256_wg_kernel<MODE, TW, NT, W, STG>), dim3(grid), dim3(G::kThreadsW), G::kLds, s, a);
-  return TFFT_OK;
+  const uint32_t capacity = static_cast<uint32_t>(p->num_cus * (8 / w));
+  const uint32_t grid = iters_dflt != 1000000u ? pick_grid(blocks, static_cast<int>(capacity), plan_iters(p->launch_iters, iters_dflt))
+                                               : rounds_grid(blocks, capacity, p->launch_iters);
+  return launch_col_row(p, key, grid, a, s);
 }
 
-template <int MODE, int TW, int W>
-int launch_col_wg_nt(const tfft_plan* p, const colfft::Args& a, hipStream_t s) {
-  // non-temporal copy-in and row stores (default; variant bit 262144 turns them off)
-  if (MODE == colfft::kColsOnLanes && !(p->variant & 1048576))   // staged full-row stores (bit 1048576: direct 16-byte pieces)
-    return p->plain_acc ? launch_col_wg<MODE, TW, false, W, true>(p, a, s) : launch_col_wg<MODE, TW, true, W, true>(p, a, s);
-  return p->plain_acc ? launch_col_wg<MODE, TW, false, W>(p, a, s) : launch_col_wg<MODE, TW, true, W>(p, a, s);
-}
-
-template <int W>
-int launch_col_wg_w(const tfft_plan* p, const Pass& ps, const colfft::Args& a, hipStream_t s) {
-  if (p->tw4_modulus) return launch_col_wg_nt<colfft::kColsInRegs, colfft::kTwFourStep, W>(p, a, s);
-  if (a.ns_f == 1)
-    return ps.tw_next ? launch_col_wg_nt<colfft::kColsOnLanes, colfft::kTwNext, W>(p, a, s)
-                      : launch_col_wg_nt<colfft::kColsOnLanes, colfft::kTwNone, W>(p, a, s);
-  return ps.tw_next ? launch_col_wg_nt<colfft::kColsInRegs, colfft::kTwNext, W>(p, a, s)
-                    : launch_col_wg_nt<colfft::kColsInRegs, colfft::kTwNone, W>(p, a, s);
-}
-
-template <bool STAGE, bool LUT>
-int launch_col_s(const tfft_plan* p, const Pass& ps, const colfft::Args& a, hipStream_t s) {
-  const bool on_lanes = (a.ns_f == 1);
-  if (on_lanes) return ps.tw_next ? launch_col_t<colfft::kColsOnLanes, colfft::kTwNext, STAGE, LUT>(p, a, s)
-                                  : launch_col_t<colfft::kColsOnLanes, colfft::kTwNone, STAGE, false>(p, a, s);
-  return ps.tw_next ? launch_col_t<colfft::kColsInRegs, colfft::kTwNext, STAGE, LUT>(p, a, s)
-                    : launch_col_t<colfft::kColsInRegs, colfft::kTwNone, STAGE, false>(p, a, s);
+// which (MODE, TW) a radix-256 pass needs: the four-step form, columns on lanes for the first pass of a plain transform
+// (Ns = 1), columns in registers otherwise
+inline void col_mode_tw(const tfft_plan* p, const Pass& ps, const colfft::Args& a, int& mode, int& tw) {
+  if (p->tw4_modulus) {
+    mode = colfft::kColsInRegs;
+    tw = colfft::kTwFourStep;
+    return;
+  }
+  mode = a.ns_f == 1 ? colfft::kColsOnLanes : colfft::kColsInRegs;
+  tw = ps.tw_next ? colfft::kTwNext : colfft::kTwNone;
 }
 
 int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipStream_t s) {
@@ -629,7 +704,8 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
 #ifdef TFFT_DEBUG_KERNELS
   a.wg_times = nullptr;
   if (debug_variants_enabled())          // measurement hook of tools/exp_wg_end_times.py
-    if (const char* e = std::getenv("TFFT_WG_TIMES_PTR")) a.wg_times = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0));
+    if (const char* e = std::getenv("TFFT_WG_TIMES_PTR"))     // (one block of 16 x 8192 words per pass of the plan)
+      a.wg_times = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0)) + (&ps - &p->passes[0]) * 16 * 8192;
   a.copy_only = (p->variant & 65536) ? 1u : 0u;
 #endif
   a.out_row_shift = p->out_row_shift;
@@ -648,72 +724,38 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     a.inv_t = 1.0 / static_cast<double>(t);
     a.a_shift = static_cast<uint32_t>(ilog2(p->n / (static_cast<uint64_t>(ps.next_radix) * ps.ns * radix)));
   }
-  if (radix == 1024) {
-    // (plan creation only emits this pass where the geometry fits: pitch, and ns_f unless it is 1, multiples of 64)
+  const bool plain = p->plain_acc;
+  const bool sc = ps.scale != 1.0f;              // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out / combine
+  if (radix == 1024 || radix == 512) {
+    // (plan creation only emits these passes where the geometry fits: pitch, and ns_f unless it is 1, multiples of 64)
     const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
     const uint32_t grid = gens_grid(blocks, static_cast<uint32_t>(p->num_cus), p->launch_iters, kGensCol8);
-    if (a.ns_f == 1) {
-      if (ps.tw_next)
-        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); }
-      else
-        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); }
-    } else {
-      if (ps.tw_next)
-        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNext, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); }
-      else if (ps.scale != 1.0f)         // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out
-        TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a);
-      else
-        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft1024_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg1024LdsBytes, s, a); }
+    const uint32_t fam = radix == 1024 ? kFam1024 : kFam512;
+    if (a.ns_f == 1) return launch_col_row(p, col_key(fam, colfft::kColsOnLanes, ps.tw_next ? colfft::kTwNext : colfft::kTwNone, false, plain), grid, a, s);
+    if (radix == 512 && p->tw4_modulus) return launch_col_row(p, col_key(fam, colfft::kColsInRegs, colfft::kTwFourStep, false, plain), grid, a, s);
+    if (ps.tw_next) return launch_col_row(p, col_key(fam, colfft::kColsInRegs, colfft::kTwNext, false, plain), grid, a, s);
+    if (radix == 512 && (((a.pitch == 256 || a.pitch == 512) && a.ns_f % 128 == 0) != ((p->variant & 268435456) != 0))) {
+      // last pass of a plan / 2D column pass by the two-round kernel (colfft512r.hpp). A/B in one process on MI355X, 8 GiB per
+      // launch (profiles/r3_ab_colfft512r.txt): the 128-column two-round form is 2-4 % faster than the 8-wave single-round
+      // kernel at row pitches of 256 and 512 columns (2^18 = 512 x 512: 335 -> 342 Gsamples/s) and at 2048, 2-4 % slower at
+      // 128, 1024 and 4096 (the 2D column pass); the default follows that, variant bit 268435456 flips the choice
+      // 128-column tiles (256-byte row segments, one 8-wave workgroup per CU) where the geometry allows and variant bit
+      // 524288 does not ask for 4-wave workgroups; otherwise 64-column tiles, two 4-wave workgroups per CU
+      const bool w8 = !(p->variant & 524288) && a.pitch % 128 == 0 && a.ns_f % 128 == 0;
+      const uint32_t grid2 = gens_grid(w8 ? blocks / 2 : blocks, static_cast<uint32_t>((w8 ? 1 : 2) * p->num_cus), p->launch_iters, kGensCol8);
+      return launch_col_row(p, col_key(kFam512R, w8 ? 8 : 4, sc, w8, !sc && plain), grid2, a, s);
     }
-    return TFFT_OK;
+    return launch_col_row(p, col_key(fam, colfft::kColsInRegs, colfft::kTwNone, sc, !sc && plain), grid, a, s);
   }
-  if (radix == 512) {
-    // plan creation only emits this pass where the geometry fits (pitch, and ns_f unless it is 1, multiples of 64)
-    const bool on_lanes = (a.ns_f == 1);
-    const uint64_t blocks = (a.tasks / a.groups) * a.pitch / 64;
-    const uint32_t grid = gens_grid(blocks, static_cast<uint32_t>(p->num_cus), p->launch_iters, kGensCol8);
-    if (on_lanes) {
-      if (ps.tw_next)
-        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
-      else
-        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsOnLanes, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
-    } else {
-      if (p->tw4_modulus)
-        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwFourStep, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwFourStep>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
-      else if (ps.tw_next)
-        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNext, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNext>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
-      else if (((a.pitch == 256 || a.pitch == 512) && a.ns_f % 128 == 0) != ((p->variant & 268435456) != 0)) {
-        // last pass of a plan / 2D column pass by the two-round kernel (colfft512r.hpp). A/B in one process on MI355X, 8 GiB per
-        // launch (profiles/r3_ab_colfft512r.txt): the 128-column two-round form is 2-4 % faster than the 8-wave single-round
-        // kernel at row pitches of 256 and 512 columns (2^18 = 512 x 512: 335 -> 342 Gsamples/s) and at 2048, 2-4 % slower at
-        // 128, 1024 and 4096 (the 2D column pass); the default follows that, variant bit 268435456 flips the choice
-        // 128-column tiles (256-byte row segments, one 8-wave workgroup per CU) where the geometry allows and variant bit
-        // 524288 does not ask for 4-wave workgroups; otherwise 64-column tiles, two 4-wave workgroups per CU
-        const bool w8 = !(p->variant & 524288) && a.pitch % 128 == 0 && a.ns_f % 128 == 0;
-        const uint32_t grid2 = gens_grid(w8 ? blocks / 2 : blocks, static_cast<uint32_t>((w8 ? 1 : 2) * p->num_cus), p->launch_iters, kGensCol8);
-        const bool sc = ps.scale != 1.0f;          // TFFT_SCALE_ONCE: the single factor in fp32 at the combine
-        if (w8 && sc)
-          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, true>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a);
-        else if (w8)
-          { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, false, true, true>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a);
-            else TFFT_LAUNCH((colfft::colfft512r_wg_kernel<8, false>), dim3(grid2), dim3(512), colfft::wg512r_lds_bytes<8>(), s, a); }
-        else if (sc)
-          TFFT_LAUNCH((colfft::colfft512r_wg_kernel<4, true>), dim3(grid2), dim3(256), colfft::wg512r_lds_bytes<4>(), s, a);
-        else
-          { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512r_wg_kernel<4, false, false, true>), dim3(grid2), dim3(256), colfft::wg512r_lds_bytes<4>(), s, a);
-            else TFFT_LAUNCH((colfft::colfft512r_wg_kernel<4, false>), dim3(grid2), dim3(256), colfft::wg512r_lds_bytes<4>(), s, a); }
-      } else if (ps.scale != 1.0f)       // TFFT_SCALE_ONCE, last pass: the single factor in fp32 at the read-out
-        TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a);
-      else
-        { if (p->plain_acc) TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone, false, true>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); else TFFT_LAUNCH((colfft::colfft512_wg_kernel<colfft::kColsInRegs, colfft::kTwNone>), dim3(grid), dim3(k4096::kThreads), colfft::kWg512LdsBytes, s, a); }
-    }
-    return TFFT_OK;
-  }
+  int mode, tw;
+  col_mode_tw(p, ps, a, mode, tw);
   // default: stores straight from registers (8- / 16-byte pieces); variant bit 4096: stage the output through
   // LDS (16-byte coalesced stores). Measured in one process on MI355X: direct wins at 2^16 and 2^20, staging at 2^13.
   // workgroup-cooperative form (full 256-byte row segments) whenever the geometry allows; variant bit 131072
   // forces the per-wave kernel
   const bool wg_allowed = !(p->variant & (131072 | 4096 | 8192));
+  // per-wave kernel: variant bit 4096 = LDS-staged stores, 8192 = twiddles from v_sin / v_cos instead of the two-level tables
+  const bool stage = p->variant & 4096, lut = !(p->variant & 8192);
   const uint64_t entries = a.tasks / a.groups;
   // narrow pitch (N = 256 pitch contiguous, columns-on-lanes form): a workgroup spans 128 / pitch whole batch
   // entries; entries that do not fill a workgroup go to the per-wave kernel in a second launch.
@@ -723,7 +765,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     if (main_entries) {
       colfft::Args am = a;
       am.tasks = static_cast<uint32_t>(main_entries * a.groups);
-      const int rc = launch_col_wg_w<8>(p, ps, am, s);
+      const int rc = launch_col_wg(p, mode, tw, 8, am, s);
       if (rc || main_entries == entries) return rc;
       a.in_re += main_entries * a.in_stride;
       a.in_im += main_entries * a.in_stride;
@@ -731,8 +773,8 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
       a.out_im += main_entries * a.out_stride;
       a.tasks = static_cast<uint32_t>((entries - main_entries) * a.groups);
     }
-    if (a.pitch % 64 == 0) return launch_col_wg_w<4>(p, ps, a, s);   // 64 columns: one 4-wave workgroup per entry
-    return launch_col_s<false, true>(p, ps, a, s);
+    if (a.pitch % 64 == 0) return launch_col_wg(p, mode, tw, 4, a, s);   // 64 columns: one 4-wave workgroup per entry
+    return launch_col_wave(p, mode, tw, false, true, a, s);
   }
   const bool wg8_ok = (a.pitch % 128 == 0) && (a.ns_f == 1 || a.ns_f % 128 == 0);
   const bool wg4_ok = (a.pitch % 64 == 0) && (a.ns_f == 1 || a.ns_f % 64 == 0);
@@ -751,12 +793,9 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   // ... also when 8-wave workgroups would leave CUs idle (single long transforms: 2^20 x 1 is 32 blocks of 128 columns)
   const bool few_blocks = entries * a.pitch / 128 < static_cast<uint64_t>(p->num_cus);
   if (wg_allowed && wg4_ok && ((p->variant & 524288) || !wg8_ok || a.pitch <= wg4_max_pitch || few_blocks))
-    return launch_col_wg_w<4>(p, ps, a, s);
-  if (wg_allowed && wg8_ok) return launch_col_wg_w<8>(p, ps, a, s);
-  // variant bit 8192: twiddles from v_sin/v_cos instead of the two-level tables
-  const bool stage = p->variant & 4096, hw = p->variant & 8192;
-  if (stage) return hw ? launch_col_s<true, false>(p, ps, a, s) : launch_col_s<true, true>(p, ps, a, s);
-  return hw ? launch_col_s<false, false>(p, ps, a, s) : launch_col_s<false, true>(p, ps, a, s);
+    return launch_col_wg(p, mode, tw, 4, a, s);
+  if (wg_allowed && wg8_ok) return launch_col_wg(p, mode, tw, 8, a, s);
+  return launch_col_wave(p, mode, tw, stage, lut, a, s);
 }
 
 template <int R>
@@ -1912,6 +1951,15 @@ int tfft_synth_uniform(void* re, void* im, uint64_t n, uint64_t batch, uint64_t 
   return TFFT_OK;
 }
 
+int tfft_kernel_list(char* buf, size_t bytes) {
+  g_err.clear();
+  std::string out;
+  for (const ColRow& r : kColTable) out += std::string(r.name) + "\n";
+  if (!buf || out.size() + 1 > bytes) return fail(TFFT_ERR_ARG, "tfft_kernel_list: buffer too small (" + std::to_string(out.size() + 1) + " bytes needed)");
+  std::memcpy(buf, out.c_str(), out.size() + 1);
+  return static_cast<int>(kColRows);
+}
+
 const char* tfft_plan_kernel_name(const tfft_plan* p) {
   if (!p) return "";
   if (p->sub_col) return tfft_plan_kernel_name(p->sub_col);
@@ -1933,7 +1981,13 @@ double tfft_plan_algorithmic_bytes(const tfft_plan* p) {
 
 double tfft_plan_mfma_flops(const tfft_plan* p) {
   if (!p) return 0.0;
-  if (p->sub_col) return tfft_plan_mfma_flops(p->sub_col) + tfft_plan_mfma_flops(p->sub_row);
+  if (p->sub_col) {
+    // the sub-plans are built for ONE chunk of the batch (launch_chain runs batch / chunk of them, plus the tail's own pair)
+    const double full = static_cast<double>(p->batch / p->chunk);
+    double f = full * (tfft_plan_mfma_flops(p->sub_col) + tfft_plan_mfma_flops(p->sub_row));
+    if (p->sub_col_tail) f += tfft_plan_mfma_flops(p->sub_col_tail) + tfft_plan_mfma_flops(p->sub_row_tail);
+    return f;
+  }
   // one radix-16 MFMA stage = 16 tiles x 2 MFMA(16x16x32) x 16384 flop per 4096 samples = 128 flop/sample
   double stages = 0;
   for (const Pass& ps : p->passes)

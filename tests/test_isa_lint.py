@@ -133,3 +133,26 @@ def test_the_dma_drain_lint_sees_what_it_should():
     clobbered = list(latch)
     clobbered[5] = "s_lshl_b64 s[8:9], s[8:9], 1"        # flag overwritten by something the lint does not follow: conservative
     assert len(findings(clobbered)) == 1
+
+
+def test_shipped_column_kernels_are_exactly_the_dispatch_table(report):
+    """The column passes are launched through ONE table (tfft.hip, TFFT_COL_* lists; tfft_kernel_list reports it). Its rows and the
+    column-kernel instantiations in the gfx950 code object must be the same set: a kernel the launch path cannot reach would be dead
+    weight in libtfft.so, a row without code cannot link."""
+    import subprocess
+
+    import tensor_fft_amd as tf
+    from tensor_fft_amd import capi
+
+    table = set(capi.kernel_list())
+    assert len(table) == len(capi.kernel_list()) and len(table) >= 60
+    mangled = [k for k in report if "colfft" in k]
+    demangled = subprocess.run(["c++filt"], input="\n".join(mangled), capture_output=True, text=True, check=True).stdout.split("\n")
+    shipped = set()
+    for d in demangled:
+        d = d.strip()
+        if not d:
+            continue
+        d = d[len("void "):] if d.startswith("void ") else d
+        shipped.add(d.split("(")[0])
+    assert shipped == table, sorted(shipped ^ table)

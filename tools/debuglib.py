@@ -1,6 +1,6 @@
 """Import FIRST in a measurement driver that needs the timing-only kernel variants, the launch-shape environment knobs
 (TFFT_*_ITERS, TFFT_PLAN_COLS, TFFT_2D_NO_FUSE) or the per-workgroup clock hook: none of that exists in the shipped
-libtfft.so. This module builds tensor-fft_amd/libtfft_debug.so (-DTFFT_DEBUG_KERNELS) if it is stale and makes
+libtfft.so. This module builds build/libtfft_debug.so (-DTFFT_DEBUG_KERNELS) if it is stale and makes
 tensor_fft_amd.load_library() pick it up. Build it in the container before a rocprofv3 run (a profiler must not see
 hipcc start under its preloaded library)."""
 import os

@@ -6,7 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import numpy as np
-dbg = torch.zeros(3 * 8192, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(4 * 16 * 8192, dtype=torch.int64, device="cuda")     # one block of 16 x 8192 words per pass of the plan
 os.environ["TFFT_WG_TIMES_PTR"] = str(dbg.data_ptr())
 os.environ["TFFT_NO_SPLIT"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +19,7 @@ p = tf.TfftPlan(n, b, 0, preserve_input=True, variant=int(os.environ.get("TFFT_V
 ws = torch.empty(p.workspace_bytes // 2, dtype=torch.float16, device="cuda"); p.set_workspace(ws)
 for _ in range(20): p.exec(x, x[n:], y, y[n:])
 torch.cuda.synchronize()
-t = dbg.cpu().numpy()           # the second pass of the last execution wrote last
+t = dbg.cpu().numpy()[int(os.environ.get("TFFT_PASS", "1")) * 16 * 8192:]           # the stamps of pass TFFT_PASS (default: the second) of the last execution
 iters = int(os.environ.get("TFFT_COLWG_ITERS", "1000000"))
 grid = min(8192, max(256, (16384 + iters - 1) // iters)) if iters < 1000000 else 256
 st, en, xcc = t[:grid].astype(np.float64), t[8192:8192 + grid].astype(np.float64), (t[16384:16384 + grid] & 15)
