@@ -221,6 +221,22 @@ int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch);
  * that names any variant bit itself gets exactly that variant. */
 int tfft_plan_default_variant(uint64_t n, uint64_t inner, uint64_t batch);
 
+/* ---- Tuner results as plan "wisdom". Replaces CreatePlan(fft_length, tuner_results_file) (src/base/Plan.h:197-255) at the level of
+ * the C ABI: the reference reads its launch parameters for one length out of the file its tuner wrote (TunerSingleFFT.cu:10-56,
+ * FileWriter.h:250-269: lines `N mode base_wpb r16_wpb r2_blocksize`). This library's tuners (examples/tuner_single_fft.cpp,
+ * tools/tuner.py) write the same lines with three more columns, `variant launch_iters batch`, and a process loads them ONCE:
+ * tfft_plan_create then gives every natural-order, contiguous-axis plan whose caller left `variant` and `launch_iters` at 0 the
+ * line of its length whose batch is nearest on a log scale (at most a factor of 8 away; a line with batch 0 fits any batch). A
+ * line with variant 0 keeps the library's default for that shape. Lines without a sixth column (a plain reference tuner file)
+ * carry nothing for this library and are skipped. Host only, process-wide, thread-safe; plans created earlier are unaffected.
+ * What belongs here rather than in the library's source: every choice whose gain is of the order of the box-to-box spread
+ * (profiles/r5_TunerResults.dat: e.g. the split of exactly two 2^24-point transforms). */
+int tfft_tuning_load(const char* path, int* lines_taken);     /* TFFT_ERR_ARG: unreadable file or a bad line (nothing is loaded then) */
+int tfft_tuning_add(uint64_t n, uint64_t batch, int variant, uint32_t launch_iters);   /* one line; replaces an earlier (n, batch) */
+void tfft_tuning_clear(void);
+/* 1 and the line's values when a loaded line applies to (n, batch), else 0 */
+int tfft_tuning_query(uint64_t n, uint64_t batch, int* variant, uint32_t* launch_iters);
+
 /* Host only: TFFT_OK if `variant` is acceptable to tfft_plan_create for (n, inner): only documented bits, no
  * combination without a compiled kernel, and no WRONG-result debugging bit unless TFFT_DEBUG_VARIANTS=1 is set.
  * CreatePlan(N, tuner_file) of the shims runs it on the file's sixth column. */

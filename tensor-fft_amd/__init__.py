@@ -16,8 +16,9 @@ Two layers, both thin:
   meaning and error behaviour, on top of :mod:`.capi`. PyTorch supplies device
   memory and streams only.
 """
-from .capi import (TfftError, TfftPlan, TfftPlan2D, device_check, lib_path, load_library, plan_cache_policy, plan_default_variant, plan_describe,  # noqa: F401
-                   ref_create_plan, synth_uniform, transposed_n2, variant_check)
+from .capi import (TfftError, TfftPlan, TfftPlan2D, device_check, kernel_list, lib_path, load_library, plan_cache_policy,  # noqa: F401
+                   plan_default_variant, plan_describe, ref_create_plan, synth_uniform, transposed_n2, tuning_add, tuning_clear,
+                   tuning_load, tuning_query, variant_check)
 from .reference_api import (  # noqa: F401
     ComputeFFT,
     CreatePlan,
@@ -32,7 +33,7 @@ from .reference_api import (  # noqa: F401
 
 __all__ = [
     "TfftError", "TfftPlan", "TfftPlan2D", "device_check", "lib_path", "load_library", "plan_cache_policy", "plan_default_variant", "plan_describe", "ref_create_plan",
-    "synth_uniform", "transposed_n2", "variant_check",
+    "synth_uniform", "transposed_n2", "variant_check", "kernel_list", "tuning_add", "tuning_clear", "tuning_load", "tuning_query",
     "ComputeFFT", "CreatePlan", "DataBatchHandler", "DataHandler", "GetMaxNoOptInSharedMem",
     "Mode_256", "Mode_4096", "Plan", "PlanWorksOnDevice",
 ]

@@ -26,6 +26,7 @@ SYMBOLS = [
     "tfft_dist_exec_pre", "tfft_dist_exec_exchange", "tfft_dist_exec_post", "tfft_dist_exec",
     "tfft_copy_h2d", "tfft_copy_d2h", "tfft_plan_prepare", "tfft_plan_opts_init", "tfft_plan_opts_known_size",
     "tfft_dist_rccl_version", "tfft_dist_comm_info", "tfft_kernel_list",
+    "tfft_tuning_load", "tfft_tuning_add", "tfft_tuning_clear", "tfft_tuning_query",
 ]
 
 LAUNCH_PERSISTENT = 65535                                     # tfft_plan_opts.launch_iters
@@ -274,6 +275,38 @@ def kernel_list():
     names = buf.value.decode().split("\n")[:-1]
     assert len(names) == rc
     return names
+
+
+def tuning_load(path):
+    """tfft_tuning_load: tuner file -> process-wide plan wisdom; returns the number of lines taken. Host only."""
+    L = load_library()
+    L.tfft_tuning_load.restype = ctypes.c_int
+    L.tfft_tuning_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    taken = ctypes.c_int(0)
+    _check(L.tfft_tuning_load(os.fsencode(path), ctypes.byref(taken)))
+    return taken.value
+
+
+def tuning_add(n, batch, variant, launch_iters=0):
+    L = load_library()
+    L.tfft_tuning_add.restype = ctypes.c_int
+    L.tfft_tuning_add.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32]
+    _check(L.tfft_tuning_add(int(n), int(batch), int(variant), int(launch_iters)))
+
+
+def tuning_clear():
+    L = load_library()
+    L.tfft_tuning_clear.restype = None
+    L.tfft_tuning_clear()
+
+
+def tuning_query(n, batch):
+    """(variant, launch_iters) of the loaded tuner line that applies to (n, batch), or None."""
+    L = load_library()
+    L.tfft_tuning_query.restype = ctypes.c_int
+    L.tfft_tuning_query.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32)]
+    v, it = ctypes.c_int(0), ctypes.c_uint32(0)
+    return (v.value, it.value) if L.tfft_tuning_query(int(n), int(batch), ctypes.byref(v), ctypes.byref(it)) else None
 
 
 def variant_check(n, inner=1, variant=0):

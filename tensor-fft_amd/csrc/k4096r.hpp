@@ -64,6 +64,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   // (stamps[(block * 8 + wave) * 8 + phase]); costs a few SALU instructions per phase and nothing when stamps == null
   unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long ph_t = 0;
+  const unsigned long long ph_entry = stamps ? __builtin_amdgcn_s_memtime() : 0;      // [7]: kernel entry -> loop start
 #define TFFT_PHASE(i)                                                  \
   if (stamps) {                                                        \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
@@ -80,21 +81,6 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave / R, s = wave % R;
-
-  for (int i = tid; i < kLdsTableBytes / 16; i += kThreads)
-    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(tables + kOffG)[i];
-  h8 f_re = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32);
-  h8 f_im = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32 + 16);
-  // (the plan builds this block with a factor 2, k4096::TableScale::tw: it gives back the headroom factor of the front end
-  // after two averaging MFMA stages, exact in fp32)
-  f4 tw_re = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
-  f4 tw_im = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
-  // The constants are operands of this statement, so the compiler has to have them in registers HERE (it waits for their
-  // loads now and knows they have landed). Left to itself it sinks these loads (restrict + const: movable across the
-  // "memory" clobber) below the first prefetch and then guards their first use, inside the loop, with s_waitcnt vmcnt(0..3),
-  // which in steady state waits for the NEXT iteration's input that was issued just before: no overlap left.
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_re), "+v"(f_im), "+v"(tw_re), "+v"(tw_im) : : "memory");
-  __syncthreads();
 
   uint8_t* const wl = lds + kLdsTableBytes + wave * kLdsWaveBytes;                 // this wave's region
   uint8_t* const gl = lds + kLdsTableBytes + (grp * R) * kLdsWaveBytes;            // region of the group's block 0
@@ -147,6 +133,24 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   };
   Rotor rot(blockIdx.x, gridDim.x);                       // (iteration order: k4096::Rotor)
   if (rot.item() < groups_total) issue_loads(rot.item());
+  // Constant operands BEHIND the first iteration's loads (round 5; before, the workgroup filled its tables, waited, and only then
+  // asked for its input: two memory round trips in a row, 1.2-1.5 us of the 9 us one transform of 2^13 ... 2^15 spends in this
+  // kernel, profiles/r5_k4096r_phases.txt). A persistent workgroup pays this once either way.
+  for (int i = tid; i < kLdsTableBytes / 16; i += kThreads)
+    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(tables + kOffG)[i];
+  h8 f_re = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32);
+  h8 f_im = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32 + 16);
+  // (the plan builds this block with a factor 2, k4096::TableScale::tw: it gives back the headroom factor of the front end
+  // after two averaging MFMA stages, exact in fp32)
+  f4 tw_re = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
+  f4 tw_im = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
+  h4 w_op = *reinterpret_cast<const h4*>(tables + kOffWR + (R == 2 ? 0 : (R == 4 ? 512 : 1024)) + lane * 8);   // radix-R front end (A operand)
+  // The constants are operands of this statement, so the compiler has to have them in registers HERE (it waits for their
+  // loads now and knows they have landed). Left to itself it sinks these loads (restrict + const: movable across the
+  // "memory" clobber) below the first prefetch and then guards their first use, inside the loop, with s_waitcnt vmcnt(0..3),
+  // which in steady state waits for the NEXT iteration's input that was issued just before: no overlap left.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_re), "+v"(f_im), "+v"(tw_re), "+v"(tw_im), "+v"(w_op) : : "memory");
+  __syncthreads();
 
   // output side of the front-end product: lane (g, n) holds rows rho' = 4 g + r: outputs s2a (r = 0, 1: re, im) and
   // s2a + 1 (r = 2, 3) of column set h'
@@ -154,7 +158,6 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   const int mm_out = s * kPs + hq;                                       // 1-KiB block of the plane this lane writes
   uint8_t* const reg_a = gl + s2a * kLdsWaveBytes + mm_out * 1024;
   uint8_t* const reg_b = reg_a + kLdsWaveBytes;
-  const h4 w_op = *reinterpret_cast<const h4*>(tables + kOffWR + (R == 2 ? 0 : (R == 4 ? 512 : 1024)) + lane * 8);
   // 1D: twiddle w_N^(m s2), m = 8 (64 mm + n + 16 j) + e: per-lane steps w_N^(s2) along e
   const float sa_re = __builtin_amdgcn_cosf(static_cast<float>(s2a) * (1.0f / kN)),
               sa_im = -__builtin_amdgcn_sinf(static_cast<float>(s2a) * (1.0f / kN));
@@ -162,14 +165,20 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
               sb_im = -__builtin_amdgcn_sinf(static_cast<float>(s2a + 1) * (1.0f / kN));
 
 #ifdef TFFT_DEBUG_KERNELS
-  if (stamps) ph_t = __builtin_amdgcn_s_memtime();
+  if (stamps) {
+    ph_t = __builtin_amdgcn_s_memtime();
+    ph_acc[7] = ph_t - ph_entry;
+  }
 #endif
   for (uint32_t it = rot.item(); it < groups_total; rot.advance(), it = rot.item()) {
 #ifdef TFFT_DEBUG_KERNELS
     if (stamps) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // this iteration's input has landed (the 16 younger operations are the previous iteration's stores)
 #endif
     TFFT_PHASE(0)
-    // a group past the end of the batch re-does the last transform (it keeps the barriers uniform) without storing
+    // A group past the end of the batch only keeps the barriers uniform: it skips the front end, the stages and the read-out.
+    // (Through round 4 it re-did the last transform without storing. For ONE transform of 2^13 that is six of eight waves doing
+    // useless work on the SIMDs the two live waves need: the phase clock showed them waiting 1.2 + 1.7 us at barriers B and C and
+    // running the stages in 2.6 us instead of 1.3: profiles/r5_k4096r_phases.txt; 2^13 x 1: 10.1 us per transform.)
     const uint32_t b_raw = ROWS ? (it >> 9) : it * kGroups + grp;      // ROWS: image index; r0 = it & 511
     const bool live = ROWS || b_raw < batch;
     const uint32_t b = live ? b_raw : batch - 1;
@@ -178,6 +187,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     // ---- radix-R front end on the matrix pipe: 32 tiles of 16 columns per wave. u_s[m] = w_N^(m s) / (2 R) sum_i x_i[m] w_R^(i s)
     // (2D rows: the scalar w_4096^(r0 s) instead of w_N^(m s)), rounded once to binary16 and written to region s in the
     // 4096 kernel's swizzled image: a lane's 8 tiles e of one j are the 8 columns of one 16-byte chunk.
+    if (live) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float ta_re, ta_im, tb_re, tb_im;                               // twiddles of outputs s2a, s2a + 1 at e = 0
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       // with all 32 tiles in one scheduling region it spills
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     TFFT_PHASE(1)
     __builtin_amdgcn_s_barrier();            // B: u_0 .. u_(R-1) are complete
@@ -236,6 +247,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     if (rot.peek() < groups_total) issue_loads(rot.peek());
     TFFT_PHASE(3)
 
+    if (live) {
     // ---- stage 1 on this wave's own region, exactly the 4096 kernel's: D1_n1[k0 = 4g + r][n0 = lane & 15]
     uint32_t pr[8][4], pi[8][4];
 #pragma unroll
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         *reinterpret_cast<u4*>(wl + 8192 + off) = u4{oim[r2][0], oim[r2][1], oim[r2][2], oim[r2][3]};
       }
     }
+    }
     if (ROWS) {
       // the row spectrum leaves from this wave's own region (no other wave needs it): row 512 s + r0 of the image
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -361,11 +374,14 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
       continue;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TFFT_PHASE(4)
     __builtin_amdgcn_s_barrier();            // C: the R spectra of every group are staged
+    TFFT_PHASE(6)
 
     // ---- interleaved read-out: X[R kk + s'] ; this wave stores output halves [4096 s, 4096 (s + 1)) of both planes
     uint16_t* const f_out_re = out_re + out_map.off(b) + out_chunk;
     uint16_t* const f_out_im = out_im + out_map.off(b) + out_chunk;
+    if (live) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t idx0 = out_chunk + 512u * i + 8u * lane;   // first output index of this lane's 16 bytes
@@ -406,17 +422,20 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         two(rb, vr);
         two(rb + 8192, vi);
       }
-      if (live) {
-        if (OTW) {       // intermediate of a transposed-input plan: plain stores, it stays in the Infinity Cache for the column pass
-          *reinterpret_cast<u4*>(f_out_re + 512 * i + 8 * lane) = vr;
-          *reinterpret_cast<u4*>(f_out_im + 512 * i + 8 * lane) = vi;
-        } else {
-          __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(f_out_re + 512 * i + 8 * lane));
-          __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(f_out_im + 512 * i + 8 * lane));
-        }
+      if (OTW) {       // intermediate of a transposed-input plan: plain stores, it stays in the Infinity Cache for the column pass
+        *reinterpret_cast<u4*>(f_out_re + 512 * i + 8 * lane) = vr;
+        *reinterpret_cast<u4*>(f_out_im + 512 * i + 8 * lane) = vi;
+      } else {
+        __builtin_nontemporal_store(vr, reinterpret_cast<u4*>(f_out_re + 512 * i + 8 * lane));
+        __builtin_nontemporal_store(vi, reinterpret_cast<u4*>(f_out_im + 512 * i + 8 * lane));
       }
     }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef TFFT_DEBUG_KERNELS
+    if (stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (measurement build: the stores acknowledged)
+#endif
+    TFFT_PHASE(5)
     __builtin_amdgcn_s_barrier();            // D: the staged spectra have been read; regions may be refilled
   }
 #ifdef TFFT_DEBUG_KERNELS

@@ -27,6 +27,7 @@
 #include "colfft.hpp"
 #include "colfft1024.hpp"
 #include "colfft512r.hpp"
+#include "collat.hpp"
 #include "permute.hpp"
 #include "stockham.hpp"
 #include "synth.hpp"
@@ -58,9 +59,10 @@ inline int ilog2(uint64_t x) {
 // ---- tfft_plan_opts.variant: which bits exist (include/tfft.h). The debugging aids give WRONG or partial results and
 // are refused unless TFFT_DEBUG_VARIANTS=1 is set in the environment of the process that creates the plan.
 constexpr int kVarK4096 = 1 | 2 | 8 | 16;
+constexpr int kVarNoLat = 1073741824;      // column passes of small work by the throughput kernels, not collat.hpp
 constexpr int kVarDebug = 4 | 64 | 128 | 65536 | (15 << 8);
 constexpr int kVarTuner = kVarK4096 | 32 | 4096 | 8192 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 |
-                          8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456 | 536870912;
+                          8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456 | 536870912 | kVarNoLat;
 // The shipped libtfft.so holds NO timing-only kernel, no environment knob and no measurement hook: all of that is compiled
 // only with -DTFFT_DEBUG_KERNELS (tensor-fft_amd/libtfft_debug.so, built on demand for the drivers under tools/), and even
 // there the debugging bits need TFFT_DEBUG_VARIANTS=1 in the environment of the process that creates the plan.
@@ -471,7 +473,10 @@ int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, vo
   // kernel does not help here (measured at 2^13: 405 / 425 / 440 / 457 Gsamples/s for 1 / 2 / 4 / all iterations)
   const uint32_t grid = gens_grid(blocks_needed, static_cast<uint32_t>(p->num_cus), p->launch_iters, kGensStatic);
 #ifdef TFFT_DEBUG_KERNELS
-#define TFFT_NO_STAMPS , static_cast<unsigned long long*>(nullptr)
+  unsigned long long* stamps1d = nullptr;      // measurement hook of tools/exp_k4096r_phases.py
+  if (debug_variants_enabled())
+    if (const char* e = std::getenv("TFFT_ROWS_STAMPS_PTR")) stamps1d = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0));
+#define TFFT_NO_STAMPS , stamps1d
 #else
 #define TFFT_NO_STAMPS
 #endif
@@ -572,7 +577,12 @@ struct Planes {
   X(8, false, true, false) X(8, false, true, true) X(8, true, true, false) X(4, false, false, false)         \
   X(4, false, false, true) X(4, true, false, false)
 
-enum : uint32_t { kFamWave = 1, kFamWg256 = 2, kFam512 = 3, kFam512R = 4, kFam1024 = 5 };
+// collat256_kernel<MODE, TW, CG, HH>: radix-256 pass for work that does not fill the chip (collat.hpp): 16 CG columns per workgroup,
+// a column group's stage 2 split over HH waves
+#define TFFT_COL_LAT_S(X, CG, HH) X(0, 0, CG, HH) X(0, 1, CG, HH) X(1, 0, CG, HH) X(1, 1, CG, HH)
+#define TFFT_COL_LAT(X) TFFT_COL_LAT_S(X, 4, 2) TFFT_COL_LAT_S(X, 2, 2) TFFT_COL_LAT_S(X, 1, 4)
+
+enum : uint32_t { kFamWave = 1, kFamWg256 = 2, kFam512 = 3, kFam512R = 4, kFam1024 = 5, kFamLat = 6 };
 using ColKernel = void (*)(colfft::Args);
 struct ColRow {
   uint32_t key;
@@ -609,6 +619,11 @@ const ColRow kColTable[] = {
   {col_key(kFam512R, W, SC, PF, PLAIN), colfft::colfft512r_wg_kernel<W, SC, PF, PLAIN>, 64 * W, colfft::wg512r_lds_bytes<W>(),  \
    "colfft::colfft512r_wg_kernel<" #W ", " #SC ", " #PF ", " #PLAIN ">"},
     TFFT_COL_512R(X)
+#undef X
+#define X(MODE, TW, CG, HH)                                                                                          \
+  {col_key(kFamLat, MODE, TW, CG, HH), colfft::collat256_kernel<MODE, TW, CG, HH>, colfft::LatGeom<CG, HH>::kThreads,        \
+   colfft::LatGeom<CG, HH>::kLds, "colfft::collat256_kernel<" #MODE ", " #TW ", " #CG ", " #HH ">"},
+    TFFT_COL_LAT(X)
 #undef X
 };
 constexpr size_t kColRows = sizeof(kColTable) / sizeof(kColTable[0]);
@@ -778,6 +793,30 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   }
   const bool wg8_ok = (a.pitch % 128 == 0) && (a.ns_f == 1 || a.ns_f % 128 == 0);
   const bool wg4_ok = (a.pitch % 64 == 0) && (a.ns_f == 1 || a.ns_f % 64 == 0);
+  // Work that does not fill the chip (the reference's single-transform benchmark, FFTBenchSinlge.cu): up to 64 blocks of 64
+  // columns (2^20 samples per pass) -> the latency kernel (collat.hpp: one memory round trip before the block is in LDS, a column
+  // group's stage 2 split over waves on different SIMDs). Variant bit 1073741824 keeps the throughput kernels (A/B, tuner).
+  // Device time per execution, latency / throughput kernels (profiles/r5_small_scan.txt): 2^16 x 1: 8.8 / 14.3 us, x 16: 13.1 /
+  // 16.3; 2^18 x 1 as 256 x 256 x 4: 12.8 / 18.1; 2^20 x 1: 18.4 / 22.2. Beyond 64 blocks the sign depends on the pass (2^16 x 32:
+  // 20.0 / 17.7, 2^21 x 1: 26.0 / 28.7, 2^17 x 32: 26.7 / 23.3): the throughput kernels keep everything from there on.
+  const uint64_t blocks64 = entries * a.pitch / 64;
+  if (wg_allowed && wg4_ok && tw != colfft::kTwFourStep && !(p->variant & kVarNoLat) && !p->launch_iters && blocks64 <= 64) {
+    // Workgroup shape (column groups of 16 per workgroup, waves per column group): stage 2 is bound by instruction issue, so the
+    // finer the split the shorter the pass - until the row segments get too narrow for the memory system (32-byte segments over
+    // 4 MiB: loads land after 2.3 us instead of 0.9, tools/lat_probe). One box, device time per transform, shapes 4 x 2 / 2 x 2 /
+    // 1 x 4 (profiles/r5_lat_shapes.txt): 2^16: 12.4 / 9.5 / 8.6 us, 2^18: 16.3 / 13.1 / 12.5, 2^19: 17.2 / 14.5 / 14.8, 2^20:
+    // 20.0 / 18.2 / 21.7.
+    const int cgs = blocks64 <= 16 ? 1 : 2;
+    const int hh = cgs == 1 ? 4 : 2;
+    int cgs_used = cgs, hh_used = hh;
+#ifdef TFFT_DEBUG_KERNELS
+    if (const uint32_t shape = env_iters("TFFT_LAT_SHAPE", 0)) {      // experiment knob: 42, 22, 14
+      cgs_used = static_cast<int>(shape / 10);
+      hh_used = static_cast<int>(shape % 10);
+    }
+#endif
+    return launch_col_row(p, col_key(kFamLat, mode, tw, cgs_used, hh_used), static_cast<uint32_t>(blocks64 * 4 / cgs_used), a, s);
+  }
   // variant bit 524288: 4-wave workgroups (two per CU) instead of one 8-wave workgroup
   static const uint32_t wg4_max_pitch_lanes = env_iters("TFFT_WG4_MAX_PITCH", 1024);          // experiment knobs
   // (the columns-in-registers form, whose output is staged behind two more barriers, gains from two workgroups per
@@ -1142,6 +1181,38 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
 //   column pass of a transposed-output plan: -1..-15 % on one data set, +-3 % on the ring, for 192 and 384 MiB; worse outside
 // Strided-axis plans (inner > 1: the 2D plan's and the distributed transform's column passes, transposed-input plans) keep the
 // streaming policy they were tuned with; the transposed-output plan decides for its column sub-plan with footprint_policy().
+// ---- plan "wisdom": tuner results loaded through the C ABI (tfft_tuning_load / tfft_tuning_add), consulted by tfft_plan_create
+// for a natural-order, contiguous-axis plan whose caller left variant AND launch_iters at 0. The file is the reference's tuner
+// file (N mode base_wpb r16_wpb r2_blocksize, Plan.h:197-255; written by FileWriter.h:250-269) with the three columns this
+// library's tuners append: variant, launch_iters, batch. Choices that one or two boxes' measurements put inside the run-to-run
+// spread live THERE, not in this source. A line applies to the batch nearest to its own on a log scale, up
+// to a factor of 8 away (the tuners write lines at batch 1, 64, 4096 and the largest that fits); batch 0 = any batch.
+struct WisdomLine {
+  uint64_t n, batch;
+  int variant;
+  uint32_t launch_iters;
+};
+std::mutex g_wisdom_mutex;
+std::vector<WisdomLine> g_wisdom;
+bool wisdom_lookup(uint64_t n, uint64_t batch, int* variant, uint32_t* launch_iters) {
+  std::lock_guard<std::mutex> lock(g_wisdom_mutex);
+  const WisdomLine* best = nullptr;
+  double best_d = 0;
+  for (const WisdomLine& w : g_wisdom) {
+    if (w.n != n) continue;
+    const double d = w.batch ? std::fabs(std::log2(static_cast<double>(batch)) - std::log2(static_cast<double>(w.batch))) : 3.0;
+    if (d > 3.0) continue;
+    if (!best || d < best_d) {
+      best = &w;
+      best_d = d;
+    }
+  }
+  if (!best) return false;
+  *variant = best->variant;
+  *launch_iters = best->launch_iters;
+  return true;
+}
+
 constexpr uint64_t kMiB = 1ull << 20;
 inline bool footprint_policy(uint64_t samples, uint64_t lo_mib) {
   const uint64_t f = samples * 12;
@@ -1158,23 +1229,26 @@ inline bool footprint_policy(uint64_t samples, uint64_t lo_mib) {
 //   2^19: 256 x 256 x 8 instead of 512 x 1024, to 2^22 samples                       x 1: 27.4 -> 22.0 us, x 4: 31.6 -> 29.2 us, x 8: 35.2 -> 32.9 us
 //   2^20: 256 x 256 x 16 instead of 1024 x 1024                                      x 1: 40.1 -> 24.1 us, x 4: 48.8 -> 38.1 us
 //   2^21: 256 x 256 x 32 instead of 512 x 512 x 8, to 2^22 samples                   x 1: 35.1 -> 30.4 us, x 2: 35.8 -> 32.9 us
-//   2^25: 512 x 256 x 256 instead of 1024 x 1024 x 32                                x 1: 198.5 -> 180.7 us (x 2: +1.5 %, not taken)
-//   2^24: 256 x 256 x 256 for exactly two transforms                                 x 2: 184.4 -> 172.7 us (three scans; x 1, x 4: the default wins)
+// Round 5: the two rules of round 4 that sat inside the recorded run-to-run spread (profiles/r4_buffer_offsets.txt: 2-5 % on fixed
+// addresses, +-5 % box to box) - 2^24 x 2 (6 %, with x 1 and x 4 going the other way) and 2^25 x 1 (9 % on one box) - are no longer
+// rules of this source: they are lines of profiles/r5_TunerResults.dat, which a caller loads with tfft_tuning_load.
 // Only variant 0 is touched: a caller (or tuner file) that names any bit gets exactly what it names.
+// Round 5: with the latency column kernel (collat.hpp) a small transform of 2^17 ... 2^21 points is fastest as 256 x 256 x R, two
+// latency passes and a radix-R tail (profiles/r5_small_scan.txt, device time per execution):
+//   2^17 x 1: 15.8 -> 11.7 us, x 8: 19.0 -> 18.0 us (x 16: 20.4 with 512 x 256 on the throughput kernels against 25.5)
+//   2^18 x 1: 19.7 -> 12.8 us, x 4: 21.7 -> 18.2 us (x 8: 24.3 with 512 x 512 against 25.9)
+//   2^19 x 1: 27.5 -> 14.7 us, 2^20 x 1: 39.9 -> 18.4 us, x 4: 47.3 -> 31.5 us, 2^21 x 1: 35.1 -> 26.6 us (as in round 4, now on the new kernel)
+// and the rules of round 4 that this scan puts inside the spread are gone (4-wave workgroups for 2^17 / 2^18 at 2^23 ... 2^25
+// samples: 35.6 / 36.1 us, 34.3 / 34.2 us, 52.8 / 52.3 us; 2^20 x 8: 51.7 / 50.8 us).
 inline int small_work_variant(uint64_t n, uint64_t inner, uint64_t batch) {
   if (inner != 1 || !is_pow2(n) || batch == 0 || batch > (1ull << 30)) return 0;
   const int lg = ilog2(n);
-  if (lg == 25) return batch == 1 ? 33554432 : 0;
-  if (lg == 24) return batch == 2 ? 33554432 : 0;
   if (lg < 17 || lg > 21) return 0;
   const uint64_t work = n * batch;
-  switch (lg) {
-    case 17: return (work >= (1ull << 23) && work <= (1ull << 25)) ? 524288 : 0;
-    case 18: return work <= (1ull << 22) ? 268435456 : (work <= (1ull << 25) ? 524288 : 0);
-    case 19: return work <= (1ull << 22) ? 33554432 : 0;
-    case 20: return work <= (1ull << 23) ? 33554432 : 0;
-    default: return work <= (1ull << 22) ? 8388608 : 0;
-  }
+  constexpr int kSplit256 = 8388608 | 33554432;          // no radix-512 / radix-1024 passes: 256 x 256 x R
+  if (work <= (lg <= 18 ? (1ull << 20) : (1ull << 22))) return kSplit256;
+  if (lg == 18 && work <= (1ull << 22)) return 268435456;  // 512 x 512 with the single-round radix-512 kernel last (round 4: x 16: 32.5 -> 28.4 us)
+  return 0;
 }
 
 inline bool cache_policy(uint64_t n, uint64_t inner, uint64_t batch) {
@@ -1365,8 +1439,17 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   constexpr bool kSubplanPolicy = false;
 #endif
   const bool caller_facing = io.group_shift == 0 && !io.rows2d && io.in_seg_len == 0 && io.otw_n == 0;
-  if (pvariant == 0 && !tw4 && order == TFFT_ORDER_NATURAL && in_order == TFFT_ORDER_NATURAL && caller_facing)
-    pvariant = small_work_variant(n, inner, batch);
+  uint32_t launch_iters = opts->launch_iters;
+  const bool plannable = !tw4 && order == TFFT_ORDER_NATURAL && in_order == TFFT_ORDER_NATURAL && caller_facing;
+  if (pvariant == 0 && launch_iters == 0 && plannable && inner == 1) {
+    int wv = 0;
+    uint32_t wi = 0;
+    if (wisdom_lookup(n, batch, &wv, &wi)) {      // a loaded tuner line for this (N, batch); variant 0 in it = the library's default
+      pvariant = wv;
+      launch_iters = wi;
+    }
+  }
+  if (pvariant == 0 && plannable) pvariant = small_work_variant(n, inner, batch);
   int rc = check_variant(n, inner, pvariant);
   if (rc) return rc;
   if (tw4 && (pvariant & (32 | 131072 | 4096 | 8192)))
@@ -1385,7 +1468,7 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
   p->out_stride = out_stride;
   p->preserve_input = opts && opts->preserve_input;
   p->variant = pvariant;
-  p->launch_iters = opts ? opts->launch_iters : 0;
+  p->launch_iters = launch_iters;
   p->scale_mode = scale_mode;
   // cache policy of the column passes: variant bit 262144 = plain accesses, 536870912 = non-temporal (streaming) accesses,
   // neither = by the plan's footprint (cache_policy)
@@ -1545,7 +1628,77 @@ int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch) {
 
 int tfft_plan_default_variant(uint64_t n, uint64_t inner, uint64_t batch) {
   if (!is_pow2(n) || !inner || !batch) return 0;
+  int wv = 0;
+  uint32_t wi = 0;
+  if (inner == 1 && wisdom_lookup(n, batch, &wv, &wi) && wv) return wv;
   return small_work_variant(n, inner, batch);
+}
+
+int tfft_tuning_add(uint64_t n, uint64_t batch, int variant, uint32_t launch_iters) {
+  g_err.clear();
+  if (!is_pow2(n) || n < 2) return fail(TFFT_ERR_NOT_POW2, "Error! Input size has to be a power of 2!");
+  if (launch_iters > TFFT_LAUNCH_PERSISTENT) return fail(TFFT_ERR_ARG, "launch_iters must be 0 .. 65535");
+  if (batch > 0xffffffffull) return fail(TFFT_ERR_ARG, "batch must be in [0, 2^32)");
+  const int rc = check_variant(n, 1, variant);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(g_wisdom_mutex);
+  for (WisdomLine& w : g_wisdom)
+    if (w.n == n && w.batch == batch) {          // a later line for the same (N, batch) replaces the earlier one
+      w.variant = variant;
+      w.launch_iters = launch_iters;
+      return TFFT_OK;
+    }
+  g_wisdom.push_back(WisdomLine{n, batch, variant, launch_iters});
+  return TFFT_OK;
+}
+
+int tfft_tuning_load(const char* path, int* lines_taken) {
+  g_err.clear();
+  if (lines_taken) *lines_taken = 0;
+  if (!path) return fail(TFFT_ERR_ARG, "null path");
+  std::FILE* f = std::fopen(path, "r");
+  if (!f) return fail(TFFT_ERR_ARG, std::string("Error! Failed to open tuner file: ") + path);
+  // parse everything first, commit only a file without a bad line
+  std::vector<WisdomLine> lines;
+  char buf[512];
+  int line_no = 0, rc = TFFT_OK;
+  while (std::fgets(buf, sizeof(buf), f)) {
+    ++line_no;
+    double len = 0;
+    long long mode = 0, bw = 0, rw = 0, r2 = 0, variant = 0, iters = 0, batch = 0;
+    const int got = std::sscanf(buf, "%lf %lld %lld %lld %lld %lld %lld %lld", &len, &mode, &bw, &rw, &r2, &variant, &iters, &batch);
+    if (got < 6) continue;                       // blank, comment, or a plain reference line (no variant column): nothing to learn
+    const uint64_t n = static_cast<uint64_t>(len);
+    if (static_cast<double>(n) != len || !is_pow2(n) || n < 2 || variant < 0 || variant > 0x7fffffffll || iters < 0 || iters > TFFT_LAUNCH_PERSISTENT ||
+        batch < 0 || batch > 0xffffffffll || check_variant(n, 1, static_cast<int>(variant)) != TFFT_OK) {
+      rc = fail(TFFT_ERR_ARG, std::string(path) + ":" + std::to_string(line_no) + ": unusable tuner line (length, variant, launch_iters or batch out of range): " +
+                                  std::string(buf).substr(0, 80));
+      break;
+    }
+    lines.push_back(WisdomLine{n, static_cast<uint64_t>(batch), static_cast<int>(variant), static_cast<uint32_t>(iters)});
+  }
+  std::fclose(f);
+  if (rc) return rc;
+  for (const WisdomLine& w : lines) {
+    const int r = tfft_tuning_add(w.n, w.batch, w.variant, w.launch_iters);
+    if (r) return r;
+  }
+  if (lines_taken) *lines_taken = static_cast<int>(lines.size());
+  return TFFT_OK;
+}
+
+void tfft_tuning_clear(void) {
+  std::lock_guard<std::mutex> lock(g_wisdom_mutex);
+  g_wisdom.clear();
+}
+
+int tfft_tuning_query(uint64_t n, uint64_t batch, int* variant, uint32_t* launch_iters) {
+  int v = 0;
+  uint32_t it = 0;
+  if (!batch || !wisdom_lookup(n, batch, &v, &it)) return 0;
+  if (variant) *variant = v;
+  if (launch_iters) *launch_iters = it;
+  return 1;
 }
 
 int tfft_variant_check(uint64_t n, uint64_t inner, int variant) {

@@ -178,7 +178,8 @@ def test_planner_pass_counts():
 # ---- select a timing-only kernel silently)
 DEBUG_VARIANTS = [4, 64, 128, 65536, 1 << 8, 3 << 8, 15 << 8, 4 | 8, 64 | 8, 524288 | 128]
 TUNER_VARIANTS = [0, 1, 2, 8, 9, 10, 16, 32, 4096, 8192, 131072, 262144, 524288, 1048576, 2097152, 4194304, 8388608,
-                  16777216, 16777216 | 8388608, 33554432, 8388608 | 33554432, 134217728, 268435456, 536870912]
+                  16777216, 16777216 | 8388608, 33554432, 8388608 | 33554432, 134217728, 268435456, 536870912, 1073741824,
+                  1073741824 | 8388608 | 33554432]
 
 
 def test_variant_check_refuses_debug_and_unknown_bits(monkeypatch):
@@ -192,7 +193,7 @@ def test_variant_check_refuses_debug_and_unknown_bits(monkeypatch):
             assert e.value.code == 5 and "TFFT_DEBUG_VARIANTS" in e.value.message
             with pytest.raises(tf.TfftError):
                 tf.plan_describe(n, 1, v)
-        for v in (1 << 30, -1, 1 << 12 | 1 << 30):
+        for v in (-1, -(1 << 30), -(1 << 12)):                # (bits 0 .. 30 all have a meaning since round 5: only the sign bit is left)
             with pytest.raises(tf.TfftError) as e:
                 capi.variant_check(n, 1, v)
             assert "unknown" in e.value.message
@@ -211,11 +212,11 @@ def test_tuner_file_with_unusable_variant_is_refused(tmp_path, capsys, monkeypat
     monkeypatch.delenv("TFFT_DEBUG_VARIANTS", raising=False)
     f = tmp_path / "TunerResults.dat"
     f.write_text("4096 4096 16 1 256 64\n65536 4096 16 1 256 65536\n1048576 4096 16 1 256 524288\n"
-                 "262144 4096 16 1 256 notanumber\n131072 4096 16 1 256 1073741824\n")
+                 "262144 4096 16 1 256 notanumber\n131072 4096 16 1 256 -5\n")
     assert tf.CreatePlan(4096, str(f)) is None                      # 64 = no-compute timing kernel
     assert tf.CreatePlan(65536, str(f)) is None                     # 65536 = copy-only column pass
     assert tf.CreatePlan(262144, str(f)) is None
-    assert tf.CreatePlan(131072, str(f)) is None                    # unknown bit
+    assert tf.CreatePlan(131072, str(f)) is None                    # not a variant at all
     assert "unusable kernel variant" in capsys.readouterr().out
     assert tf.CreatePlan(1 << 20, str(f))._variant == 524288
 

@@ -263,7 +263,7 @@ def test_debug_variants_are_refused_at_plan_creation(tf, monkeypatch):
             tf.TfftPlan(n, 2, 0, variant=v)
         assert "TFFT_DEBUG_VARIANTS" in e.value.message
     with pytest.raises(tf.TfftError):
-        tf.TfftPlan(4096, 2, 0, variant=1 << 30)
+        tf.TfftPlan(4096, 2, 0, variant=-(1 << 30))
     monkeypatch.setenv("TFFT_DEBUG_VARIANTS", "1")       # the shipped library has no such kernels, whatever the environment says
     with pytest.raises(tf.TfftError):
         tf.TfftPlan(1 << 21, 2, 0, variant=1 << 8)

@@ -105,24 +105,26 @@ def test_cache_policy_follows_the_footprint():
 
 
 def test_small_work_gets_the_split_with_more_workgroups():
-    """tfft_plan_default_variant (host only): what variant 0 means for a natural-order plan that does not fill the chip
-    (profiles/r4_small_batch_scan.txt); from the measured limits on, and for every other length, it is 0."""
+    """tfft_plan_default_variant (host only): what variant 0 means for a natural-order plan that does not fill the chip. Round 5:
+    256 x 256 x R on the latency column kernel for 2^17 ... 2^21 up to the measured limits (profiles/r5_small_scan.txt); from the
+    limits on, and for every other length, it is 0; the two within-noise rules of round 4 (2^24 x 2, 2^25 x 1) live in
+    profiles/r5_TunerResults.dat now (tests/test_round5_host.py)."""
     V, D = tf.plan_default_variant, tf.plan_describe
-    assert V(1 << 20, 1, 1) == 33554432 and V(1 << 20, 1, 8) == 33554432 and V(1 << 20, 1, 16) == 0 and V(1 << 20, 1, 1024) == 0
+    S = 8388608 | 33554432
+    assert V(1 << 20, 1, 1) == S and V(1 << 20, 1, 4) == S and V(1 << 20, 1, 8) == 0 and V(1 << 20, 1, 1024) == 0
     assert D(1 << 20, 1, V(1 << 20, 1, 1)) == "col:256+tw col:256+tw autosort:16-tw" and D(1 << 20, 1, V(1 << 20, 1, 1024)) == "col:1024+tw col:1024"
-    assert V(1 << 19, 1, 8) == 33554432 and V(1 << 19, 1, 16) == 0
+    assert V(1 << 19, 1, 8) == S and V(1 << 19, 1, 16) == 0
     assert D(1 << 19, 1, V(1 << 19, 1, 1)) == "col:256+tw col:256+tw autosort:8-tw"
-    assert V(1 << 18, 1, 16) == 268435456 and V(1 << 18, 1, 32) == 524288 and V(1 << 18, 1, 64) == 524288 and V(1 << 18, 1, 128) == 524288 and V(1 << 18, 1, 256) == 0
-    assert D(1 << 18, 1, V(1 << 18, 1, 1)) == "col:512+tw col:512"            # same split, the other radix-512 kernel
-    assert V(1 << 21, 1, 2) == 8388608 and V(1 << 21, 1, 4) == 0
+    assert V(1 << 18, 1, 1) == S and V(1 << 18, 1, 4) == S and V(1 << 18, 1, 8) == 268435456 and V(1 << 18, 1, 16) == 268435456 and V(1 << 18, 1, 32) == 0
+    assert D(1 << 18, 1, V(1 << 18, 1, 1)) == "col:256+tw col:256+tw autosort:4-tw" and D(1 << 18, 1, V(1 << 18, 1, 16)) == "col:512+tw col:512"
+    assert V(1 << 21, 1, 2) == S and V(1 << 21, 1, 4) == 0
     assert D(1 << 21, 1, V(1 << 21, 1, 1)) == "col:256+tw col:256+tw autosort:32-tw"
-    for lg in (8, 12, 16, 17, 22, 24, 26):
-        assert V(1 << lg, 1, 1) == 0
-    assert V(1 << 17, 1, 32) == 0 and V(1 << 17, 1, 64) == 524288 and V(1 << 17, 1, 256) == 524288 and V(1 << 17, 1, 512) == 0
-    assert V(1 << 24, 1, 2) == 33554432 and V(1 << 24, 1, 3) == 0 and D(1 << 24, 1, 33554432) == "col:256+tw col:256+tw col:256"
-    assert V(1 << 25, 1, 1) == 33554432 and V(1 << 25, 1, 2) == 0 and D(1 << 25, 1, 33554432) == "col:512+tw col:256+tw col:256"
+    assert V(1 << 17, 1, 1) == S and V(1 << 17, 1, 8) == S and V(1 << 17, 1, 16) == 0 and V(1 << 17, 1, 64) == 0
+    assert D(1 << 17, 1, V(1 << 17, 1, 1)) == "col:256+tw col:256+tw autosort:2-tw"
+    for lg in (8, 12, 16, 22, 24, 25, 26):
+        assert V(1 << lg, 1, 1) == 0 and V(1 << lg, 1, 2) == 0
     assert V(1 << 20, 64, 1) == 0 and V(3 << 19, 1, 1) == 0 and V(1 << 20, 1, 0) == 0
-    for lg, b in ((17, 64), (18, 1), (18, 64), (19, 4), (20, 8), (21, 1), (24, 2), (25, 1)):                          # every value it returns is a variant the library accepts
+    for lg, b in ((17, 1), (18, 1), (18, 16), (19, 4), (20, 4), (21, 1)):                          # every value it returns is a variant the library accepts
         capi.variant_check(1 << lg, 1, V(1 << lg, 1, b))
 
 

@@ -1,6 +1,7 @@
 """Which split is fastest when the work does not fill the chip? The default splits come from a scan at 2^30 samples per launch
 (tools/plan_scan.py); a single 2^20-point transform is 16 workgroups of the radix-1024 kernel on 256 CUs. Times every planner
-variant per (N, batch), executions back to back on one stream (no host synchronisation between them), median of rounds.
+variant per (N, batch): device time per execution, 8 executions per HIP graph (round 5: with passes of 4-6 us an eager loop
+measures the host's launch rate, not the plan), median of rounds.
     python tools/scan_small_batch.py [--min-log2 16] [--max-log2 24] [--max-total-log2 25] [--variants 0,32,...]"""
 import argparse, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--min-log2", type=int, default=16)
 ap.add_argument("--max-log2", type=int, default=24)
 ap.add_argument("--max-total-log2", type=int, default=25)
-ap.add_argument("--variants", default="0,32,131072,524288,8388608,33554432,41943040,268435456,268959744,42467328")
+ap.add_argument("--variants", default="0,1073741824,524288,8388608,33554432,41943040,1115684864,268435456,268959744,42467328")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=5)
 args = ap.parse_args()
@@ -38,15 +39,26 @@ for lg in range(args.min_log2, args.max_log2 + 1):
                 p.set_workspace(ws)
             for _ in range(3):
                 p.exec(x, x[n:], y, y[n:])
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                with torch.cuda.graph(gr, stream=st):
+                    for _ in range(8):
+                        p.exec(x, x[n:], y, y[n:], stream=st.cuda_stream)
+            torch.cuda.synchronize()
+            gr.replay()
             ts = []
+            reps = max(1, args.reps // 8)
             for _ in range(args.rounds):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(args.reps):
-                    p.exec(x, x[n:], y, y[n:])
+                for _ in range(reps):
+                    gr.replay()
                 e1.record()
                 torch.cuda.synchronize()
-                ts.append(e0.elapsed_time(e1) / args.reps * 1e3)
+                ts.append(e0.elapsed_time(e1) / reps / 8 * 1e3)
+            del gr
             row[v] = (statistics.median(ts), p.num_launches, tf.plan_describe(n, 1, v or tf.plan_default_variant(n, 1, b)))
             p.close()
         best = min(row, key=lambda v: row[v][0])
