@@ -206,6 +206,81 @@ def other_configs(torch, tf, orc, device):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
+    def check_bins(x, y, n, what):
+        """Parseval and four spectrum bins of ONE transform against direct fp64 DFT sums on the device (for lengths whose full
+        fp64 oracle transform on the host would take tens of seconds)."""
+        xs, ys = x[:2 * n].double(), y[:2 * n].double()
+        e_in = float((xs * xs).sum()) / n
+        e_out = float((ys * ys).sum())
+        if not abs(e_out - e_in) / e_in < 5e-3:
+            raise CheckFailed(f"self-check failed: {what} Parseval {e_out} vs {e_in}")
+        t = torch.arange(n, device="cuda", dtype=torch.float64)
+        zr, zi = xs[:n], xs[n:]
+        worst = 0.0
+        for k in (1, 4097 % n, n // 3, n - 5):
+            ph = -2.0 * np.pi * ((t * k) % n) / n
+            c, sn = torch.cos(ph), torch.sin(ph)
+            er = float((zr * c - zi * sn).sum()) / n
+            ei = float((zr * sn + zi * c).sum()) / n
+            worst = max(worst, abs(float(y[k]) - er), abs(float(y[n + k]) - ei))
+        rms = (e_in / n / 2) ** 0.5
+        if not worst < 8 * 2.0 ** -11 * max(rms, 2.0 ** -14):
+            raise CheckFailed(f"self-check failed: {what} bins off by {worst:.3e} (spectrum rms {rms:.3e})")
+        return f"Parseval + 4 bins against a direct fp64 DFT sum on the device: max |delta| {worst:.2e} (spectrum rms {rms:.2e})"
+
+    def reference_protocol_single():
+        """The reference's own benchmark protocol (src/testing/benchmarks/FFTBenchSinlge.cu:11-15, Bench.h:121-142): ONE transform per
+        length, N = 2^12, 2^13, ... Reported: DEVICE time per transform, 16 executions captured in one HIP graph and replayed (the
+        reference's wall clock around ComputeFFT + synchronise is ~10 us of host time on top, whatever the length;
+        examples/bench_single.cpp runs that protocol itself from C++ and prints both). Every length is checked: the full fp64
+        oracle transform up to 2^20, Parseval + 4 direct bins beyond."""
+        rows = {}
+        for lg in range(12, 27):
+            n = 1 << lg
+            x = torch.empty(2 * n, dtype=torch.float16, device="cuda")
+            tf.synth_uniform(x, x[n:], n, 1, seed=SEED + lg)
+            y = torch.empty_like(x)
+            plan = tf.TfftPlan(n, 1, device, preserve_input=True)
+            ws = torch.empty(max(1, plan.workspace_bytes // 2), dtype=torch.float16, device="cuda")
+            if plan.workspace_bytes:
+                plan.set_workspace(ws)
+            plan.exec(x, x[n:], y, y[n:])
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                with torch.cuda.graph(gr, stream=st):
+                    for _ in range(16):
+                        plan.exec(x, x[n:], y, y[n:], stream=st.cuda_stream)
+            torch.cuda.synchronize()
+            reps = 16 if lg <= 22 else 4
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.03:          # clock ramp
+                gr.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(7):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    gr.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / reps / 16 * 1e3)
+            ts.sort()
+            if lg <= 20:
+                err = check_transforms(torch, orc, y, n, 1, [0], seed=SEED + lg)
+                check = f"vs the fp64 oracle: rel-L2 {err:.2e}"
+            else:
+                check = check_bins(x, y, n, f"single N=2^{lg}")
+            rows[f"2^{lg}"] = {"device_us": ts[len(ts) // 2], "device_us_min": ts[0], "passes": plan.num_launches,
+                               "plan": tf.plan_describe(n, 1, tf.plan_default_variant(n, 1, 1)), "check": check}
+            plan.close()
+            del gr
+        return {"protocol": "one transform per length (FFTBenchSinlge.cu:11-15); device time per transform, 16 executions per HIP graph, "
+                            "median of 7 rounds; input uniform(-1,1) from the counter-hash generator",
+                "lengths": rows}
+
     cases = (("n256_x_1048576", 256, 1 << 20, "natural"), ("n1024_x_262144", 1024, 1 << 18, "natural"),
              ("n8192_x_32768", 8192, 1 << 15, "natural"), ("n65536_x_4096", 1 << 16, 1 << 12, "natural"),
              ("configs[2]_n2^20_x_1024", 1 << 20, 1024, "natural"),
@@ -247,27 +322,20 @@ def other_configs(torch, tf, orc, device):
             check = f"transforms 0 and {b - 1} vs the fp64 oracle: rel-L2 {err:.2e}"
         else:
             # 2^26: the full fp64 oracle transform takes ~30 s of host time; check Parseval and 4 bins computed directly
-            xs = x.float()
-            e_in = float((xs * xs).sum()) / n
-            ys = y.float()
-            e_out = float((ys * ys).sum())
-            if not abs(e_out - e_in) / e_in < 5e-3:
-                raise CheckFailed(f"self-check failed: N=2^26 Parseval {e_out} vs {e_in}")
-            t = torch.arange(n, device="cuda", dtype=torch.float64)
-            zr, zi = x[:n].double(), x[n:2 * n].double()
-            worst = 0.0
-            for k in (1, 4097, n // 3, n - 5):
-                ph = -2.0 * np.pi * ((t * k) % n) / n
-                c, s = torch.cos(ph), torch.sin(ph)
-                er = float((zr * c - zi * s).sum()) / n
-                ei = float((zr * s + zi * c).sum()) / n
-                gr, gi = float(y[k]), float(y[n + k])
-                worst = max(worst, abs(gr - er), abs(gi - ei))
-            rms = (e_in / n / 2) ** 0.5
-            if not worst < 8 * 2.0 ** -11 * max(rms, 2.0 ** -14):
-                raise CheckFailed(f"self-check failed: N=2^26 bins off by {worst:.3e} (spectrum rms {rms:.3e})")
-            check = f"Parseval + 4 bins against a direct fp64 DFT sum on the device: max |delta| {worst:.2e} (spectrum rms {rms:.2e})"
-        return {"gsamples_per_s": n * b / ms / 1e6, "ms": ms, "passes": plan.num_launches, "check": check}
+            check = check_bins(x, y, n, "N=2^26")
+        rep = {"gsamples_per_s": n * b / ms / 1e6, "ms": ms, "passes": plan.num_launches, "check": check}
+        if order != "natural":
+            rep.update(chunked_roofline(n * b / ms / 1e6, plan.workspace_bytes // (4 * n), "transforms"))
+        return rep
+
+    def chunked_roofline(gsamples, chunk, unit):
+        """A chunked two-pass plan runs both passes of a chunk back to back through one chunk-sized workspace, so that the second pass
+        finds the intermediate in the 256-MiB Infinity Cache. Two ways to price it against the 8 TB/s HBM roofline:
+        16 B per sample (both passes' reads and writes counted as memory traffic: SURVEY 8d's two-pass figure) and 8 B per sample
+        (the intermediate never leaves the die: only the caller's input and output are HBM traffic). The truth lies between; the
+        A/B against whole-batch passes on one box is under profiles/."""
+        return {"chunk": chunk, "chunk_unit": unit, "roofline_16B": {"achieved_GBps": gsamples * 16, "frac": gsamples * 16 / HBM_PEAK_GBS},
+                "roofline_8B": {"achieved_GBps": gsamples * 8, "frac": gsamples * 8 / HBM_PEAK_GBS}}
 
     for name, n, b, order in cases:
         guarded(name, lambda: entry_1d(n, b, order))     # noqa: B023 (called at once)
@@ -290,10 +358,13 @@ def other_configs(torch, tf, orc, device):
         err = _rel_l2(got, exact)
         if not err < REL_L2_TOL:
             raise CheckFailed(f"self-check failed: 2D 4096x4096 rel-L2 error {err:.3e} vs the CPU oracle")
-        return {"gsamples_per_s": half / ms / 1e6, "ms": ms, "passes": plan2.num_launches,
-                "check": f"image {b} vs the fp64 oracle (rows, then columns): rel-L2 {err:.2e}"}
+        rep = {"gsamples_per_s": half / ms / 1e6, "ms": ms, "passes": plan2.num_launches,
+               "check": f"image {b} vs the fp64 oracle (rows, then columns): rel-L2 {err:.2e}"}
+        rep.update(chunked_roofline(half / ms / 1e6, plan2.workspace_bytes // (4 * rows * cols), "images"))
+        return rep
 
     guarded("configs[3]_2d_4096x4096_x_64", entry_2d)
+    guarded("reference_protocol_single", reference_protocol_single)
     return out
 
 
@@ -379,6 +450,25 @@ def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm
             raise
         why = str(e)
         f = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="torch")
+    try:
+        return _dist_2pow26_body(torch, tf, dist, rank, world, f, n, why, want_native, self_via_comm, reps, capi)
+    finally:
+        f.close()          # the plan, its 512 MiB of buffers and the communicator go whatever happened above
+
+
+def _agree(torch, dist, world, ok_local):
+    """All ranks learn whether ANY of them failed (one MIN all-reduce): a local exception then ends the entry on every rank
+    together instead of leaving the others inside the next collective until the watchdog fires."""
+    if world == 1:
+        return bool(ok_local)
+    t = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t[0]))
+
+
+def _dist_2pow26_body(torch, tf, dist, rank, world, f, n, why, want_native, self_via_comm, reps, capi):
+    import numpy as np
+
     g = f.geometry
     n1, n2, c, k = int(g.n1), int(g.n2), int(g.cols), int(g.rows)
     comm_info = None
@@ -402,20 +492,27 @@ def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm
             dist.all_reduce(token)
             torch.cuda.synchronize()
 
-    for _ in range(3):
+    local_err = None
+    ms, ph, re, im = 0.0, {"pre_ms": 0.0, "exchange_ms": 0.0, "post_ms": 0.0}, None, None
+    try:
+        for _ in range(3):
+            re, im = f.forward(in_re, in_im)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            re, im = f.forward(in_re, in_im)
+        fence()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        # the three phases, each between two HIP events on the stream all of them are enqueued on
+        fence()
+        ph = f.phase_times(in_re, in_im, reps)
+        fence()
         re, im = f.forward(in_re, in_im)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        re, im = f.forward(in_re, in_im)
-    fence()
-    ms = (time.perf_counter() - t0) / reps * 1e3
-    # the three phases, each between two HIP events on the stream all of them are enqueued on
-    fence()
-    ph = f.phase_times(in_re, in_im, reps)
-    fence()
-    re, im = f.forward(in_re, in_im)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+    except Exception as e:      # noqa: BLE001
+        local_err = f"{type(e).__name__}: {e}"
+    if not _agree(torch, dist, world, local_err is None):
+        return {"error": local_err or "another rank failed inside the timed section of the distributed transform (its stderr has the reason)"}
     keys = ("pre_ms", "exchange_ms", "post_ms")
     t_max = torch.tensor([ms] + [ph[q] for q in keys], dtype=torch.float64, device="cuda")
     t_min = t_max.clone()
@@ -436,7 +533,7 @@ def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm
         "bytes_through_the_collective_per_rank": sent,
         "exchange_GBps_per_rank": (sent / (phases["exchange_ms"]["max_over_ranks"] * 1e-3) / 1e9) if sent else None,
     }
-    # ---- checks
+    # ---- checks: Parseval over all ranks, and on EVERY rank four bins of its own slice of the spectrum against direct fp64 sums
     xs = x.double()
     e_in = float((xs * xs).sum()) / n
     e_out = (re.double() ** 2).sum() + (im.double() ** 2).sum()
@@ -464,9 +561,8 @@ def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm
     if not worst < 8 * 2.0 ** -11 * max(rms, 2.0 ** -14):
         report["error"] = f"self-check failed: distributed N=2^26 bins off by {worst:.3e} (spectrum rms {rms:.3e})"
         return report
-    report["check"] = (f"Parseval over all ranks + 4 bins per rank against a direct fp64 DFT sum on the device: max |delta| {worst:.2e} "
-                       f"(spectrum rms {rms:.2e})")
-    f.close()
+    report["check"] = (f"Parseval over all ranks + 4 bins of every rank's own slice against a direct fp64 DFT sum on the device: max |delta| "
+                       f"over the ranks {worst:.2e} (spectrum rms {rms:.2e})")
     return report
 
 
@@ -504,6 +600,8 @@ def main():
 
     import __graft_entry__ as g
 
+    # recompiled here, or the prebuilt library that travelled with the tree (build() is mtime-based)?
+    build_mode = "reused: prebuilt libtfft.so newer than its sources" if g.is_current() else "recompiled by this run"
     g.build()
     import tensor_fft_amd as tf
 
@@ -602,6 +700,22 @@ def main():
     if not par < 5e-3:
         raise SystemExit(f"self-check failed: Parseval mismatch {par:.3e}")
 
+    if dist is not None and world > 1:
+        # every rank checks one sampled transform of ITS OWN slice against the CPU oracle (a wrong slice on rank 5 must not pass
+        # because rank 0's is right); the worst error travels to rank 0, a failure on any rank ends the run on all of them
+        from oracle import orc as orc_all
+
+        try:
+            mine_err = check_transforms(torch, orc_all, y, N, batch, [(7919 * (rank + 1)) % batch], first_fft=first_fft)
+        except CheckFailed:
+            mine_err = float("inf")
+        worst_rank = torch.tensor([min(mine_err, 1e30)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(worst_rank, op=dist.ReduceOp.MAX)
+        per_rank_err = float(worst_rank[0])
+        if not per_rank_err < REL_L2_TOL:
+            raise SystemExit(f"self-check failed: a rank's own slice is off by rel-L2 {per_rank_err:.3e} vs the CPU oracle")
+    else:
+        per_rank_err = None
     if rank == 0:
         from oracle import orc
 
@@ -642,7 +756,8 @@ def main():
                 "cold_ms_per_step": cold_ms,
                 "parallelism": f"batch sharded over {world} GPU(s), no data-path collective",
                 "self_check": f"transforms {ids} of rank 0's timed output vs the CPU oracle's fp64 DFT/N: rel-L2 {oracle_err:.2e}; "
-                              f"Parseval on 64 transforms per rank: {par:.1e}",
+                              f"Parseval on 64 transforms per rank: {par:.1e}"
+                              + (f"; one sampled transform of EVERY rank's own slice vs the oracle: worst rel-L2 {per_rank_err:.2e}" if per_rank_err is not None else ""),
             },
             "roofline": {
                 "bound": "hbm",
@@ -667,6 +782,8 @@ def main():
             "visible_gpus": torch.cuda.device_count(),
             "device": torch.cuda.get_device_name(local_rank),
             "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none",
+            "build_mode": build_mode,
+            "library": tf.lib_path() if hasattr(tf, "lib_path") else None,
         }
         if world == 1 and not args.no_other_configs and not args.only_dist_entry and batch == BATCH:
             x = y = None

@@ -4,8 +4,8 @@
 // hipMemcpy; the library's pinned ring, tfft_copy_h2d) are driven with a long queue of transforms in front of the copy:
 // the LAST queued transform must still see signal A. exit 0 / 1.
 //
-// usage: copy_order_check [log2_N = 17] [queued transforms = 2000]   (a length whose plan leaves the input block intact: an even
-// number of passes, 2^16 .. 2^18 for a single transform; the odd-pass lengths - a single 2^19 .. 2^21 takes three since round 4,
+// usage: copy_order_check [log2_N = 16] [queued transforms = 2000]   (a length whose plan leaves the input block intact: an even
+// number of passes, 2^16 for a single transform; the odd-pass lengths - a single 2^17 .. 2^21 takes three since round 5,
 // tfft_plan_default_variant - use it as scratch, the reference's contract, ComputeFFT.h:89-93)
 #include <cstdio>
 #include <cstdlib>
@@ -15,7 +15,7 @@
 #include "tensor_fft.hpp"
 
 int main(int argc, char** argv) {
-  const int lg = argc > 1 ? std::atoi(argv[1]) : 17;
+  const int lg = argc > 1 ? std::atoi(argv[1]) : 16;
   const int queued = argc > 2 ? std::atoi(argv[2]) : 2000;
   const int n = 1 << lg;
   auto maybe_plan = CreatePlan(n, Mode_4096, 16, 1, 256);

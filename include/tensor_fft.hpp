@@ -212,6 +212,10 @@ inline PlanCache& plan_cache() {
   return c;
 }
 inline tfft_plan* exec_plan(uint64_t n, uint64_t batch, int variant, std::string* err, int launch_iters = 0) {
+  if (tfft_abi_version() != TFFT_ABI_VERSION) {      // the struct layouts this translation unit was compiled with (tfft.h)
+    *err = "libtfft.so speaks ABI " + std::to_string(tfft_abi_version()) + ", this program was built against ABI " + std::to_string(TFFT_ABI_VERSION);
+    return nullptr;
+  }
   std::mutex& lock = plan_cache().lock;
   auto& cache = plan_cache().plans;
   int dev = 0;

@@ -28,6 +28,14 @@ extern "C" {
 
 typedef struct tfft_plan tfft_plan;
 
+/* ABI version of this header. 1: the layouts of rounds 1-3 (tfft_plan_opts began with in_batch_stride, tfft_dist_geometry with n).
+ * 2 (round 4 on): both structs begin with struct_size / reserved_ - an incompatible change of every field offset, which is why
+ * the number exists: a binding compares tfft_abi_version() of the library it loaded with the TFFT_ABI_VERSION it was built
+ * against and refuses to continue on a mismatch (include/tensor_fft.hpp and tensor-fft_amd/capi.py do). Appending fields, new
+ * entry points and new flag / variant bits do NOT change it. */
+#define TFFT_ABI_VERSION 2
+int tfft_abi_version(void);
+
 /* Status codes. 0 = success, mirroring the reference's `std::nullopt == OK`
  * convention (src/base/ComputeFFT.h:147-150); the message of the last failure on
  * the calling thread is available from tfft_last_error(). */
@@ -95,13 +103,17 @@ int tfft_max_no_optin_shared_mem(int device_id);
  * (N <= 32768 with a contiguous axis) have no such restriction. */
 typedef struct tfft_plan_opts {
   uint32_t struct_size; /* sizeof(tfft_plan_opts) AS THE CALLER WAS COMPILED (TFFT_PLAN_OPTS_INIT / tfft_plan_opts_init set it).
-                           The struct grows by appending fields (48 bytes: through output_order; 64: + fourstep_n,
-                           fourstep_col0; 72: + launch_iters and input_order, which share one 8-byte slot); the library reads
-                           exactly struct_size bytes and takes every field beyond them as 0, so a
-                           caller built against an older header keeps working against a newer library. Accepted: the size of
-                           every released layout (tfft_plan_opts_known_size); 0 and anything else is refused with TFFT_ERR_ARG
-                           instead of being read past its end. The reference's boundary is source level (default arguments of
-                           CreatePlan, src/base/Plan.h:77-82) and never had this problem; a C ABI does. */
+                           From ABI version 2 on (TFFT_ABI_VERSION below: the version that put this field in front) the struct
+                           grows only by appending fields, the library reads exactly struct_size bytes and takes every field
+                           beyond them as 0: a caller built against THIS header or a later one keeps working against a newer
+                           library. Accepted sizes: 72 (the whole struct of ABI 2) and its two documented prefixes, 48 (through
+                           output_order) and 64 (+ fourstep_n, fourstep_col0), for bindings that declare only the leading
+                           fields (tfft_plan_opts_known_size); 0 and anything else is refused with TFFT_ERR_ARG instead of being
+                           read past its end. NOT compatible: binaries built against the ABI-1 header, whose struct began with
+                           in_batch_stride (they are refused where the stride reads as an unknown size and cannot be told apart
+                           where it reads as 48, 64 or 72: rebuild them; tfft_abi_version() lets a binding check). The
+                           reference's boundary is source level (default arguments of CreatePlan, src/base/Plan.h:77-82) and
+                           never had this problem; a C ABI does. */
   uint32_t reserved_;   /* must be 0 */
   uint64_t in_batch_stride;
   uint64_t out_batch_stride;
@@ -338,6 +350,7 @@ typedef struct tfft_dist_geometry {
   int fused;           /* 1: the four-step twiddle rides in the column pass's epilogue (always, today) */
   int reorder;         /* 1: a re-order pass [p'][k][c] -> [k][p' C + c] runs in front of the row transforms; 0: they read the segments in place */
   int local_passes;    /* passes over this rank's N / world samples per transform */
+  int slabs;           /* (since round 5; it occupies what was padding) column slabs of the plan: 1, or 2 / 4 with TFFT_DIST_SLABS_* */
 } tfft_dist_geometry;
 #define TFFT_DIST_GEOMETRY_INIT {(uint32_t)sizeof(tfft_dist_geometry)}
 
@@ -367,7 +380,15 @@ int tfft_dist_rccl_version(int* version);
 /*        TFFT_DIST_CALLER_BUFFERS = the plan allocates NO exchange buffers of its own (4 planes of N / world halves: 512 MiB at
  * N = 2^26 on one rank): the caller hands its own in with tfft_dist_plan_set_buffers before the first execution, e.g. tensors that
  * a framework's own collective can send. */
-enum { TFFT_DIST_SELF_VIA_COMM = 1, TFFT_DIST_CALLER_BUFFERS = 2 };
+/*        TFFT_DIST_SLABS_2 / TFFT_DIST_SLABS_4 (round 5) = the exchange overlaps the column pass: the rank's C columns are cut into 2 / 4
+ *        slabs, each its own launch of the column kernel and its own ncclSend / ncclRecv group; tfft_dist_exec enqueues the groups on
+ *        a second stream of the plan, each behind the event of its slab's column pass, so slab s crosses xGMI while slab s + 1 is
+ *        being computed, and the row transforms wait for the last group. The exchange buffers then hold [peer][slab][k][c_s] (a
+ *        peer's chunk is still one contiguous K C block, so a caller-run exchange on tfft_dist_plan_buffers is unchanged), the
+ *        result is bit-identical to a plan without the flag. Needs N1 = 256, no re-order pass and slabs of whole 128-column
+ *        blocks (TFFT_ERR_ARG otherwise). The three separate phase calls run the same slabs one after the other on one stream.
+ *        Default (no flag): one slab, everything on the caller's stream, as before. */
+enum { TFFT_DIST_SELF_VIA_COMM = 1, TFFT_DIST_CALLER_BUFFERS = 2, TFFT_DIST_SLABS_2 = 4, TFFT_DIST_SLABS_4 = 8 };
 int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* comm, int flags, tfft_dist_plan** out);
 void tfft_dist_plan_destroy(tfft_dist_plan* plan);
 int tfft_dist_plan_geometry(const tfft_dist_plan* plan, tfft_dist_geometry* out);

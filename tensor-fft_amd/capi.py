@@ -26,8 +26,9 @@ SYMBOLS = [
     "tfft_dist_exec_pre", "tfft_dist_exec_exchange", "tfft_dist_exec_post", "tfft_dist_exec",
     "tfft_copy_h2d", "tfft_copy_d2h", "tfft_plan_prepare", "tfft_plan_opts_init", "tfft_plan_opts_known_size",
     "tfft_dist_rccl_version", "tfft_dist_comm_info", "tfft_kernel_list",
-    "tfft_tuning_load", "tfft_tuning_add", "tfft_tuning_clear", "tfft_tuning_query",
+    "tfft_tuning_load", "tfft_tuning_add", "tfft_tuning_clear", "tfft_tuning_query", "tfft_abi_version",
 ]
+ABI_VERSION = 2                                               # TFFT_ABI_VERSION this binding's struct mirrors were written against
 
 LAUNCH_PERSISTENT = 65535                                     # tfft_plan_opts.launch_iters
 SCALE_SEQUENTIAL, SCALE_NONE, SCALE_ONCE = 0, 1, 2           # tfft_plan_opts.scale
@@ -92,7 +93,7 @@ class DistGeometry(ctypes.Structure):
         ("struct_size", ctypes.c_uint32), ("reserved_", ctypes.c_uint32),
         ("n", ctypes.c_uint64), ("n1", ctypes.c_uint64), ("n2", ctypes.c_uint64), ("cols", ctypes.c_uint64),
         ("rows", ctypes.c_uint64), ("chunk", ctypes.c_uint64), ("world", ctypes.c_int), ("rank", ctypes.c_int),
-        ("fused", ctypes.c_int), ("reorder", ctypes.c_int), ("local_passes", ctypes.c_int),
+        ("fused", ctypes.c_int), ("reorder", ctypes.c_int), ("local_passes", ctypes.c_int), ("slabs", ctypes.c_int),
     ]
 
 
@@ -102,7 +103,7 @@ class DistGeometry(ctypes.Structure):
 
 
 DIST_ID_BYTES = 128
-DIST_SELF_VIA_COMM, DIST_CALLER_BUFFERS = 1, 2          # tfft_dist_plan_create flags
+DIST_SELF_VIA_COMM, DIST_CALLER_BUFFERS, DIST_SLABS_2, DIST_SLABS_4 = 1, 2, 4, 8          # tfft_dist_plan_create flags
 
 
 def lib_path():
@@ -133,6 +134,9 @@ def load_library():
     import torch  # noqa: F401
 
     L = ctypes.CDLL(path)
+    L.tfft_abi_version.restype = ctypes.c_int
+    if L.tfft_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path} speaks ABI {L.tfft_abi_version()}, this binding was written against ABI {ABI_VERSION}: rebuild the library")
     vp, u64, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
     L.tfft_ref_create_plan.restype = ci
     L.tfft_ref_create_plan.argtypes = [u64, ci, ci, ci, ci, ctypes.POINTER(RefPlanStruct)]
@@ -551,12 +555,16 @@ class DistPlan:
     comm: a DistComm (the RCCL exchange then runs inside exec()) or None (pre() / post() only: the caller moves the
     chunks between them, over whatever transport it has; `buffers=` hands in its own send / receive tensors)."""
 
-    def __init__(self, n, world, rank, device=0, comm=None, buffers=None, self_via_comm=False):
+    def __init__(self, n, world, rank, device=0, comm=None, buffers=None, self_via_comm=False, slabs=1):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         self._comm = comm
+        if slabs not in (1, 2, 4):
+            raise TfftError(5, "slabs must be 1, 2 or 4")
         # caller-owned exchange buffers: the plan then allocates none of its own (TFFT_DIST_CALLER_BUFFERS; 512 MiB at 2^26 on one rank)
-        flags = (DIST_SELF_VIA_COMM if self_via_comm else 0) | (DIST_CALLER_BUFFERS if buffers is not None else 0)
+        # slabs > 1: the exchange overlaps the column pass slab by slab inside exec() (TFFT_DIST_SLABS_*)
+        flags = ((DIST_SELF_VIA_COMM if self_via_comm else 0) | (DIST_CALLER_BUFFERS if buffers is not None else 0)
+                 | {1: 0, 2: DIST_SLABS_2, 4: DIST_SLABS_4}[slabs])
         _check(self._lib.tfft_dist_plan_create(int(n), int(world), int(rank), int(device), comm.handle if comm else None,
                                                flags, ctypes.byref(self._h)))
         self.device = int(device)

@@ -95,6 +95,15 @@ struct Args {
   // samples, K C apart (tfft_dist_*; no re-order pass). Off: shift 31, gap 0.
   uint32_t in_seg_shift;
   uint64_t in_seg_gap;
+  // Column slab of a four-step radix-256 pass (kTwFourStep forms of colfft256_wg_kernel only; a transform distributed over several
+  // GPUs with its exchange overlapped slab by slab, dist.hpp): the launch covers column blocks [blk_first, blk_first + blk_count)
+  // (blk_count 0 = all), and output row k of flattened column m goes to
+  //     (k << out_pitch_shift) + (k >> out_seg_shift) * out_seg_gap + (m - out_col0) + out_base        halves
+  // The defaults (out_pitch_shift = ns_f_shift, out_seg_shift = 31, everything else 0) are the plain [k][m] matrix; a slab writes
+  // the send layout [peer q][slab s][k][c_s], whose (q, s) pieces are contiguous for ncclSend.
+  uint32_t blk_first, blk_count;
+  uint32_t out_pitch_shift, out_seg_shift;
+  uint64_t out_seg_gap, out_col0, out_base;
   const float2* tw_lo;
   const float2* tw_hi;
   const uint8_t* tables;            // k4096::build_tables blob
@@ -459,7 +468,10 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
   // columns of one entry; for a narrower pitch (columns-on-lanes form only) it spans 16 W / pitch whole entries,
   // whose rows are then contiguous in memory (N = 256 pitch), so the copy-in still moves full lines.
   const uint32_t pshift = static_cast<uint32_t>(__builtin_ctzll(a.pitch));
-  const uint32_t total = static_cast<uint32_t>(((a.tasks / a.groups) << pshift) / G::kCols);
+  // (four-step forms: a launch may cover a slab of the pass's column blocks only, Args::blk_first / blk_count)
+  const uint32_t blk_first = (TW == kTwFourStep) ? a.blk_first : 0u;
+  const uint32_t total = (TW == kTwFourStep && a.blk_count) ? a.blk_count
+                                                            : static_cast<uint32_t>(((a.tasks / a.groups) << pshift) / G::kCols);
 
   // (adjacent column blocks run on different CUs at the same time: measured 1-2 % faster than giving each
   // workgroup a contiguous range of blocks)
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
   // copy-in of block blk_in (LDS-DMA, asynchronous): issued for the first block AHEAD of the table fetch below, for every further
   // block at the end of the iteration before it (the loop's increment expression; the image is free by then, barrier D)
   auto copy_in = [&](uint32_t blk_in) {
-    const uint64_t gc0 = static_cast<uint64_t>(blk_in) * G::kCols;
+    const uint64_t gc0 = static_cast<uint64_t>(blk_in + blk_first) * G::kCols;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t sr = 32 * wave + 4 * i + (lane >> 4);
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
     return nb;
   };
   for (uint32_t blk = blk0; blk < total; blk = next_block()) {
-    const uint64_t gc0 = static_cast<uint64_t>(blk) * G::kCols;        // first flattened column of the block
+    const uint64_t gc0 = static_cast<uint64_t>(blk + blk_first) * G::kCols;   // first flattened column of the block
     const uint64_t gcw = gc0 + 16 * wave;                              // ... of this wave
     const uint64_t bidx = gcw >> pshift;                               // this wave's batch entry
     const uint64_t mb = gc0 & (a.pitch - 1);                           // first column of the block (pitch >= 16 W)
@@ -757,7 +769,10 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
           vr = u4{vr.z, vr.w, vr.x, vr.y};
           vi = u4{vi.z, vi.w, vi.x, vi.y};
         }
-        const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
+        const uint64_t o = (TW == kTwFourStep)
+                               ? (mb - a.out_col0) + a.out_base + (static_cast<uint64_t>(k) << a.out_pitch_shift) +
+                                     static_cast<uint64_t>(k >> a.out_seg_shift) * a.out_seg_gap + 8 * chunk
+                               : obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
         if (NT) {
           TFFT_ST_PASS(TW, vr, reinterpret_cast<u4*>(o_re + o));
           TFFT_ST_PASS(TW, vi, reinterpret_cast<u4*>(o_im + o));

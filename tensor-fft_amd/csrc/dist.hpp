@@ -145,6 +145,7 @@ int dist_geometry(uint64_t n, int world, int rank, tfft_dist_geometry* g) {
                    pitch % 128 == 0 && g->cols >= pitch;
   g->reorder = (world > 1 && !seg) ? 1 : 0;
   g->local_passes = 1 + g->reorder + static_cast<int>(passes.size());
+  g->slabs = 1;
   return TFFT_OK;
 }
 
@@ -163,6 +164,14 @@ struct tfft_dist_plan {
   _Float16 *tmp_re = nullptr, *tmp_im = nullptr;
   bool self_via_comm = false;   // TFFT_DIST_SELF_VIA_COMM: the own chunk goes through ncclSend / ncclRecv too
   bool caller_buffers = false;  // TFFT_DIST_CALLER_BUFFERS: no internal exchange block; tfft_dist_plan_set_buffers before the first exec
+  // Round 5: the C columns of the column pass in S slabs (TFFT_DIST_SLABS_2 / _4). Slab s is its own launch of the column kernel
+  // and its own ncclSend / ncclRecv group; tfft_dist_exec puts the groups on a second stream, each behind the event of its slab's
+  // column pass, so slab s travels over xGMI while slab s + 1 is being computed. Buffers: send [q][s][k][c_s], receive
+  // [p'][s][k][c_s] (what rank p' sent for this rank); the row transforms read P S segments of C / S samples per row.
+  int slabs = 1;
+  hipStream_t comm_stream = nullptr;
+  std::vector<hipEvent_t> slab_done;
+  hipEvent_t exchange_done = nullptr;
 };
 
 extern "C" {
@@ -282,13 +291,14 @@ void tfft_dist_plan_destroy(tfft_dist_plan* p) {
   if (!p) return;
   tfft_plan_destroy(p->col);
   tfft_plan_destroy(p->row);
-  if (p->block) {
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    (void)hipSetDevice(p->device);
-    (void)hipFree(p->block);
-    (void)hipSetDevice(prev);
-  }
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(p->device);
+  if (p->block) (void)hipFree(p->block);
+  for (hipEvent_t e : p->slab_done) (void)hipEventDestroy(e);
+  if (p->exchange_done) (void)hipEventDestroy(p->exchange_done);
+  if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
+  (void)hipSetDevice(prev);
   delete p;
 }
 
@@ -296,7 +306,8 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
   g_err.clear();
   if (!out) return fail(TFFT_ERR_ARG, "null plan pointer");
   *out = nullptr;
-  if (flags & ~(TFFT_DIST_SELF_VIA_COMM | TFFT_DIST_CALLER_BUFFERS)) return fail(TFFT_ERR_ARG, "unknown flag");
+  if (flags & ~(TFFT_DIST_SELF_VIA_COMM | TFFT_DIST_CALLER_BUFFERS | TFFT_DIST_SLABS_2 | TFFT_DIST_SLABS_4)) return fail(TFFT_ERR_ARG, "unknown flag");
+  if ((flags & TFFT_DIST_SLABS_2) && (flags & TFFT_DIST_SLABS_4)) return fail(TFFT_ERR_ARG, "TFFT_DIST_SLABS_2 and TFFT_DIST_SLABS_4 exclude each other");
   if ((flags & TFFT_DIST_SELF_VIA_COMM) && !comm) return fail(TFFT_ERR_ARG, "TFFT_DIST_SELF_VIA_COMM needs a communicator");
   tfft_dist_geometry g;
   int rc = dist_geometry(n, world, rank, &g);
@@ -312,12 +323,23 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
                                     ", the plan was asked for rank " + std::to_string(rank) + " of " + std::to_string(world));
   }
   tfft_dist_plan* p = new tfft_dist_plan;
+  g.slabs = (flags & TFFT_DIST_SLABS_4) ? 4 : ((flags & TFFT_DIST_SLABS_2) ? 2 : 1);
   p->g = g;
   p->device = device_id;
   p->comm = static_cast<ncclComm_t>(comm);
   p->self_via_comm = (flags & TFFT_DIST_SELF_VIA_COMM) != 0;
   p->caller_buffers = (flags & TFFT_DIST_CALLER_BUFFERS) != 0;
   const bool two_sided = world > 1 || p->self_via_comm;      // separate receive buffers
+  p->slabs = (flags & TFFT_DIST_SLABS_4) ? 4 : ((flags & TFFT_DIST_SLABS_2) ? 2 : 1);
+  if (p->slabs > 1) {
+    // a slab is whole 128-column blocks of ONE four-step radix-256 column pass, and the row transforms must be able to read the
+    // received pieces in place (segments of C / S samples no shorter than a row of their first column pass)
+    if (g.n1 != 256 || g.reorder || (g.cols / static_cast<uint64_t>(p->slabs)) % 128) {
+      const std::string why = g.n1 != 256 ? "its column pass is radix 512" : (g.reorder ? "its row transforms need the re-order pass" : "a slab would be narrower than 128 columns");
+      delete p;
+      return fail(TFFT_ERR_ARG, "TFFT_DIST_SLABS_*: this geometry cannot overlap its exchange (" + why + "); create the plan without the flag");
+    }
+  }
   auto bail = [&](int code) {
     const std::string keep = g_err;
     tfft_dist_plan_destroy(p);
@@ -340,12 +362,27 @@ int tfft_dist_plan_create(uint64_t n, int world, int rank, int device_id, void* 
   ro.out_batch_stride = g.n2;
   ro.preserve_input = 1;
   InternalOpts ri;
-  if (!g.reorder && world > 1) {
-    ri.in_seg_len = g.cols;
-    ri.in_seg_stride = g.chunk;
+  if (!g.reorder && (world > 1 || p->slabs > 1)) {
+    ri.in_seg_len = g.cols / static_cast<uint64_t>(p->slabs);
+    ri.in_seg_stride = g.chunk / static_cast<uint64_t>(p->slabs);
+    ro.in_batch_stride = ri.in_seg_len;
   }
   rc = create_plan(g.n2, g.rows, device_id, &ro, ri, &p->row);
   if (rc) return bail(rc);
+  if (p->slabs > 1) {
+    int prev = 0;
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess) e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking);
+    for (int i = 0; e == hipSuccess && i < p->slabs; ++i) {
+      hipEvent_t ev = nullptr;
+      e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e == hipSuccess) p->slab_done.push_back(ev);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->exchange_done, hipEventDisableTiming);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return bail(hip_fail(e, "stream / events of the overlapped exchange"));
+  }
   const size_t plane = static_cast<size_t>(g.n / static_cast<uint64_t>(world)) * sizeof(_Float16);   // N / P halves
   const size_t row_ws = tfft_plan_workspace_bytes(p->row);
   // (TFFT_DIST_CALLER_BUFFERS: the exchange buffers come from the caller, e.g. tensors of a framework whose own collective
@@ -444,29 +481,34 @@ int dist_check(const tfft_dist_plan* p) {
 }
 }  // namespace
 
-int tfft_dist_exec_pre(const tfft_dist_plan* p, const void* in_re, const void* in_im, void* stream) {
-  g_err.clear();
-  int rc = dist_check(p);
-  if (rc) return rc;
-  if (!in_re || !in_im) return fail(TFFT_ERR_ARG, "null data pointer");
-  if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im)) & 15) return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
-  return launch_chain(p->col, in_re, in_im, p->send_re, p->send_im, static_cast<hipStream_t>(stream));
+namespace {
+// column pass of slab sl (all of it for S = 1) into the send buffers
+int dist_launch_col(const tfft_dist_plan* p, int sl, const void* in_re, const void* in_im, hipStream_t s) {
+  if (p->slabs == 1) return launch_chain(p->col, in_re, in_im, p->send_re, p->send_im, s);
+  const uint64_t cs = p->g.cols / static_cast<uint64_t>(p->slabs);            // columns per slab
+  g_slab.on = true;
+  g_slab.col_first = static_cast<uint64_t>(sl) * cs;
+  g_slab.col_count = cs;
+  g_slab.out_pitch_shift = static_cast<uint32_t>(ilog2(cs));                 // row k of the piece: k (C / S)
+  g_slab.out_seg_shift = static_cast<uint32_t>(ilog2(p->g.rows));            // k / K = destination rank q
+  g_slab.out_seg_gap = p->g.chunk - p->g.chunk / static_cast<uint64_t>(p->slabs);   // q K C - q K C / S
+  g_slab.out_base = static_cast<uint64_t>(sl) * (p->g.chunk / static_cast<uint64_t>(p->slabs));
+  const int rc = launch_chain(p->col, in_re, in_im, p->send_re, p->send_im, s);
+  g_slab = SlabCtx{};
+  return rc;
 }
 
-int tfft_dist_exec_exchange(const tfft_dist_plan* p, void* stream) {
-  g_err.clear();
-  int rc = dist_check(p);
-  if (rc) return rc;
+// slab sl of chunk q (both planes) goes to rank q: one ncclGroupStart / Send + Recv per peer and plane / GroupEnd on s
+int dist_exchange_slab(const tfft_dist_plan* p, int sl, hipStream_t s) {
   const int world = p->g.world, me = p->g.rank;
   if (world == 1 && !p->self_via_comm) return TFFT_OK;
   if (!p->comm) return fail(TFFT_ERR_COMM, "this plan was created without a communicator: run the exchange yourself between "
                                            "tfft_dist_exec_pre and tfft_dist_exec_post (chunk q of the send buffers goes to rank q)");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t chunk = static_cast<size_t>(p->g.chunk);
+  const size_t chunk = static_cast<size_t>(p->g.chunk), piece = chunk / static_cast<size_t>(p->slabs), off = static_cast<size_t>(sl) * piece;
   // own chunk: device-to-device copy, ordered on the same stream (or, with TFFT_DIST_SELF_VIA_COMM, a send to itself)
   if (!p->self_via_comm) {
-    TFFT_HIP(hipMemcpyAsync(p->recv_re + me * chunk, p->send_re + me * chunk, chunk * sizeof(_Float16), hipMemcpyDeviceToDevice, s));
-    TFFT_HIP(hipMemcpyAsync(p->recv_im + me * chunk, p->send_im + me * chunk, chunk * sizeof(_Float16), hipMemcpyDeviceToDevice, s));
+    TFFT_HIP(hipMemcpyAsync(p->recv_re + me * chunk + off, p->send_re + me * chunk + off, piece * sizeof(_Float16), hipMemcpyDeviceToDevice, s));
+    TFFT_HIP(hipMemcpyAsync(p->recv_im + me * chunk + off, p->send_im + me * chunk + off, piece * sizeof(_Float16), hipMemcpyDeviceToDevice, s));
   }
   Rccl* r = rccl();
   TFFT_NCCL(r->GroupStart());
@@ -474,16 +516,41 @@ int tfft_dist_exec_exchange(const tfft_dist_plan* p, void* stream) {
     // peers in a rotated order: at step d rank r sends to r + d and receives from r - d, so the P ranks' first
     // transfers do not all target the same GPU
     const int to = (me + d) % world, from = (me - d + world) % world;
-    ncclResult_t e = r->Send(p->send_re + to * chunk, chunk, ncclHalf, to, p->comm, s);
-    if (e == ncclSuccess) e = r->Send(p->send_im + to * chunk, chunk, ncclHalf, to, p->comm, s);
-    if (e == ncclSuccess) e = r->Recv(p->recv_re + from * chunk, chunk, ncclHalf, from, p->comm, s);
-    if (e == ncclSuccess) e = r->Recv(p->recv_im + from * chunk, chunk, ncclHalf, from, p->comm, s);
+    ncclResult_t e = r->Send(p->send_re + to * chunk + off, piece, ncclHalf, to, p->comm, s);
+    if (e == ncclSuccess) e = r->Send(p->send_im + to * chunk + off, piece, ncclHalf, to, p->comm, s);
+    if (e == ncclSuccess) e = r->Recv(p->recv_re + from * chunk + off, piece, ncclHalf, from, p->comm, s);
+    if (e == ncclSuccess) e = r->Recv(p->recv_im + from * chunk + off, piece, ncclHalf, from, p->comm, s);
     if (e != ncclSuccess) {
       (void)r->GroupEnd();
       return nccl_fail(e, "ncclSend / ncclRecv");
     }
   }
   TFFT_NCCL(r->GroupEnd());
+  return TFFT_OK;
+}
+}  // namespace
+
+int tfft_dist_exec_pre(const tfft_dist_plan* p, const void* in_re, const void* in_im, void* stream) {
+  g_err.clear();
+  int rc = dist_check(p);
+  if (rc) return rc;
+  if (!in_re || !in_im) return fail(TFFT_ERR_ARG, "null data pointer");
+  if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im)) & 15) return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
+  for (int sl = 0; sl < p->slabs; ++sl) {
+    rc = dist_launch_col(p, sl, in_re, in_im, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+  }
+  return TFFT_OK;
+}
+
+int tfft_dist_exec_exchange(const tfft_dist_plan* p, void* stream) {
+  g_err.clear();
+  int rc = dist_check(p);
+  if (rc) return rc;
+  for (int sl = 0; sl < p->slabs; ++sl) {
+    rc = dist_exchange_slab(p, sl, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+  }
   return TFFT_OK;
 }
 
@@ -504,7 +571,30 @@ int tfft_dist_exec_post(const tfft_dist_plan* p, void* out_re, void* out_im, voi
 }
 
 int tfft_dist_exec(const tfft_dist_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im, void* stream) {
-  int rc = tfft_dist_exec_pre(p, in_re, in_im, stream);
+  int rc;
+  if (p && p->slabs > 1 && (p->g.world > 1 || p->self_via_comm) && p->comm) {
+    // overlapped: slab s's exchange on the plan's second stream behind the event of its column pass, while slab s + 1 computes on
+    // the caller's stream; the row transforms wait for the last exchange. (The three separate calls run the same slabs one after
+    // the other on one stream: same buffers, same results, separable phases.)
+    g_err.clear();
+    rc = dist_check(p);
+    if (rc) return rc;
+    if (!in_re || !in_im) return fail(TFFT_ERR_ARG, "null data pointer");
+    if ((reinterpret_cast<uintptr_t>(in_re) | reinterpret_cast<uintptr_t>(in_im)) & 15) return fail(TFFT_ERR_ARG, "data pointers must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int sl = 0; sl < p->slabs; ++sl) {
+      rc = dist_launch_col(p, sl, in_re, in_im, s);
+      if (rc) return rc;
+      TFFT_HIP(hipEventRecord(p->slab_done[static_cast<size_t>(sl)], s));
+      TFFT_HIP(hipStreamWaitEvent(p->comm_stream, p->slab_done[static_cast<size_t>(sl)], 0));
+      rc = dist_exchange_slab(p, sl, p->comm_stream);
+      if (rc) return rc;
+    }
+    TFFT_HIP(hipEventRecord(p->exchange_done, p->comm_stream));
+    TFFT_HIP(hipStreamWaitEvent(s, p->exchange_done, 0));
+    return tfft_dist_exec_post(p, out_re, out_im, stream);
+  }
+  rc = tfft_dist_exec_pre(p, in_re, in_im, stream);
   if (rc) return rc;
   rc = tfft_dist_exec_exchange(p, stream);
   if (rc) return rc;

@@ -362,16 +362,6 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
   const uint32_t stride_b = gridDim.x * kWavesPerBlock;
   uint32_t b = blockIdx.x * kWavesPerBlock + wave;
 
-  // Work that does not fill the chip (every wave has at most ONE transform: the reference's single-transform benchmark,
-  // FFTBenchSinlge.cu:11-15): the transform's copy goes out FIRST and the tables are fetched behind it, one memory round trip
-  // instead of two in a row. With more work per wave the order below stands: issuing the first copy ahead of the table fill was
-  // measured 9-20 % SLOWER at batch 65536 (the workgroups then start their HBM reads in lock-step, profiles/r1_k4096_grid_scan.txt).
-  const bool copy_first = !(V & kNoCompute) && gridDim.x * kWavesPerBlock >= batch;    // (not in the timing-only copy kernels of the measurement build)
-  if (copy_first) {
-    const uint32_t bb = b < batch ? b : batch - 1;       // (a wave past the end copies the last transform: it keeps this branch uniform)
-    dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(bb)),
-             reinterpret_cast<const uint8_t*>(in_im + in_map.off(bb)), wl_off, lane);
-  }
   // G and H into LDS, once per workgroup.
   for (int i = tid; i < kLdsTableBytes / 16; i += kThreads)
     reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(tables + kOffG)[i];
@@ -383,9 +373,11 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // table loads retired: vmcnt below counts only loop traffic
   __syncthreads();
   if (b >= batch) return;
-  if (!copy_first)
-    dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(b)),
-             reinterpret_cast<const uint8_t*>(in_im + in_map.off(b)), wl_off, lane);
+  // (Issuing this first copy ahead of the table fill was measured 9-20 % SLOWER at batch 65536: workgroups then start their HBM
+  // reads in lock-step, profiles/r1_k4096_grid_scan.txt. Round 5 tried it again for ONE transform, where it would save a memory
+  // round trip on paper: 5.5 us per transform against 4.9 in this order, 6.2 when the idle waves copied as well. Not kept.)
+  dma_in<(V & kNonTemporal) != 0>(reinterpret_cast<const uint8_t*>(in_re + in_map.off(b)),
+           reinterpret_cast<const uint8_t*>(in_im + in_map.off(b)), wl_off, lane);
 
   const uint8_t* const g_tab = lds + lane * 16;
   const uint8_t* const h_tab = lds + 16384 + lane * 16;

@@ -81,6 +81,25 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave / R, s = wave % R;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+  // (Round 5 tried the first iteration's loads AHEAD of this table fill, one memory round trip instead of two: 7.0 / 8.0 us per
+  // transform at 2^13 / 2^14 against 7.2 / 7.9 in this order: nothing, so the order of rounds 1-4 stands.)
+  for (int i = tid; i < kLdsTableBytes / 16; i += kThreads)
+    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(tables + kOffG)[i];
+  h8 f_re = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32);
+  h8 f_im = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32 + 16);
+  // (the plan builds this block with a factor 2, k4096::TableScale::tw: it gives back the headroom factor of the front end
+  // after two averaging MFMA stages, exact in fp32)
+  f4 tw_re = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
+  f4 tw_im = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
+  h4 w_op = *reinterpret_cast<const h4*>(tables + kOffWR + (R == 2 ? 0 : (R == 4 ? 512 : 1024)) + lane * 8);   // radix-R front end (A operand)
+  // The constants are operands of this statement, so the compiler has to have them in registers HERE (it waits for their
+  // loads now and knows they have landed). Left to itself it sinks these loads (restrict + const: movable across the
+  // "memory" clobber) below the first prefetch and then guards their first use, inside the loop, with s_waitcnt vmcnt(0..3),
+  // which in steady state waits for the NEXT iteration's input that was issued just before: no overlap left.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_re), "+v"(f_im), "+v"(tw_re), "+v"(tw_im), "+v"(w_op) : : "memory");
+  __syncthreads();
 
   uint8_t* const wl = lds + kLdsTableBytes + wave * kLdsWaveBytes;                 // this wave's region
   uint8_t* const gl = lds + kLdsTableBytes + (grp * R) * kLdsWaveBytes;            // region of the group's block 0
@@ -108,12 +127,14 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   // front end of iteration i has consumed these registers and fly under the three MFMA stages, the read-out and the
   // stores of iteration i (the LDS-DMA version of round 1 started its copy-in after the last barrier and waited for it:
   // one 160-KiB workgroup per CU, 3.6-3.9 TB/s, 35 % of the wave time parked in s_waitcnt / s_barrier).
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   const int fg = lane >> 4, fn = lane & 15;
   u4 raw[4][4];
   auto issue_loads = [&](uint32_t it) {
     const uint32_t b_raw = ROWS ? (it >> 9) : it * kGroups + grp;
-    const uint32_t b = (ROWS || b_raw < batch) ? b_raw : batch - 1;     // past the end: re-read the last transform
+    // a group past the end of the batch loads nothing (round 5: it used to re-read the last transform, harmless in a full batch,
+    // but for ONE transform of 2^13 that is 128 KiB through the CU's load path instead of 32 KiB)
+    if (!ROWS && __builtin_amdgcn_readfirstlane(static_cast<int>(b_raw >= batch))) return;
+    const uint32_t b = b_raw;
     const uint32_t r0 = it & 511;
     const uint64_t base = in_map.off(b) + (ROWS ? static_cast<uint64_t>(r0) * 4096 : 0);
     constexpr uint64_t kBlockStep = ROWS ? 512ull * 4096 : 4096ull;     // block i of the group: rows r0 + 512 i, or samples 4096 i
@@ -131,26 +152,9 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
         raw[j][jj] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src + 128 * j));
     }
   };
+
   Rotor rot(blockIdx.x, gridDim.x);                       // (iteration order: k4096::Rotor)
   if (rot.item() < groups_total) issue_loads(rot.item());
-  // Constant operands BEHIND the first iteration's loads (round 5; before, the workgroup filled its tables, waited, and only then
-  // asked for its input: two memory round trips in a row, 1.2-1.5 us of the 9 us one transform of 2^13 ... 2^15 spends in this
-  // kernel, profiles/r5_k4096r_phases.txt). A persistent workgroup pays this once either way.
-  for (int i = tid; i < kLdsTableBytes / 16; i += kThreads)
-    reinterpret_cast<u4*>(lds)[i] = reinterpret_cast<const u4*>(tables + kOffG)[i];
-  h8 f_re = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32);
-  h8 f_im = *reinterpret_cast<const h8*>(tables + kOffF1 + lane * 32 + 16);
-  // (the plan builds this block with a factor 2, k4096::TableScale::tw: it gives back the headroom factor of the front end
-  // after two averaging MFMA stages, exact in fp32)
-  f4 tw_re = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32);
-  f4 tw_im = *reinterpret_cast<const f4*>(tables + kOffTw + lane * 32 + 16);
-  h4 w_op = *reinterpret_cast<const h4*>(tables + kOffWR + (R == 2 ? 0 : (R == 4 ? 512 : 1024)) + lane * 8);   // radix-R front end (A operand)
-  // The constants are operands of this statement, so the compiler has to have them in registers HERE (it waits for their
-  // loads now and knows they have landed). Left to itself it sinks these loads (restrict + const: movable across the
-  // "memory" clobber) below the first prefetch and then guards their first use, inside the loop, with s_waitcnt vmcnt(0..3),
-  // which in steady state waits for the NEXT iteration's input that was issued just before: no overlap left.
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_re), "+v"(f_im), "+v"(tw_re), "+v"(tw_im), "+v"(w_op) : : "memory");
-  __syncthreads();
 
   // output side of the front-end product: lane (g, n) holds rows rho' = 4 g + r: outputs s2a (r = 0, 1: re, im) and
   // s2a + 1 (r = 2, 3) of column set h'

@@ -97,6 +97,15 @@ int lds_opt_in(const void* fn, int device, int bytes) {
 }
 // prepare mode: walk the launch logic of a plan, run lds_opt_in for every kernel it selects, launch nothing
 thread_local bool g_prepare = false;
+// Column slab of a four-step radix-256 pass (dist.hpp: the exchange of a distributed transform overlapped slab by slab): set around
+// a launch_chain call by tfft_dist_exec*, read by launch_col. Columns, not blocks: the block width is chosen at the launch site.
+struct SlabCtx {
+  bool on = false;
+  uint64_t col_first = 0, col_count = 0;
+  uint32_t out_pitch_shift = 0, out_seg_shift = 31;
+  uint64_t out_seg_gap = 0, out_base = 0;
+};
+thread_local SlabCtx g_slab;
 #define TFFT_LAUNCH(kernel, grid, block, lds, stream, ...)                                        \
   do {                                                                                            \
     const int rc_ = lds_opt_in(reinterpret_cast<const void*>(kernel), p->device, (lds));          \
@@ -654,9 +663,17 @@ int launch_col_wave(const tfft_plan* p, int mode, int tw, bool stage, bool lut, 
 }
 
 // workgroup-cooperative radix-256 kernel, W = 4 or 8 waves
-int launch_col_wg(const tfft_plan* p, int mode, int tw, int w, const colfft::Args& a, hipStream_t s) {
+int launch_col_wg(const tfft_plan* p, int mode, int tw, int w, const colfft::Args& a_in, hipStream_t s) {
   const uint32_t cols = 16u * static_cast<uint32_t>(w);
-  const uint64_t blocks = (a.tasks / a.groups) * a.pitch / cols;
+  colfft::Args a = a_in;
+  uint64_t blocks = (a.tasks / a.groups) * a.pitch / cols;
+  if (g_slab.on) {                      // a slab of the pass's columns (whole blocks: the distributed plan checks the divisibility)
+    if (g_slab.col_first % cols || g_slab.col_count % cols || tw != colfft::kTwFourStep)
+      return fail(TFFT_ERR_ARG, "internal error: column slab not a whole number of blocks of a four-step pass");
+    a.blk_first = static_cast<uint32_t>(g_slab.col_first / cols);
+    a.blk_count = static_cast<uint32_t>(g_slab.col_count / cols);
+    blocks = a.blk_count;
+  }
   // non-temporal copy-in and row stores unless the plan's cache policy says plain (tfft_plan_cache_policy, variant bit 262144);
   // columns-on-lanes form: staged full-row stores (variant bit 1048576: direct 16-byte pieces)
   const bool nt = !p->plain_acc;
@@ -716,6 +733,22 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   const bool first_pass = &ps == &p->passes[0];
   a.in_seg_shift = first_pass ? p->in_seg_shift : 31;
   a.in_seg_gap = first_pass ? p->in_seg_gap : 0;
+  a.blk_first = 0;
+  a.blk_count = 0;
+  a.out_pitch_shift = static_cast<uint32_t>(ilog2(ps.ns * p->inner));
+  a.out_seg_shift = 31;
+  a.out_seg_gap = 0;
+  a.out_col0 = 0;
+  a.out_base = 0;
+  if (g_slab.on) {
+    if (!(p->tw4_modulus && ps.radix == 256 && p->passes.size() == 1))
+      return fail(TFFT_ERR_ARG, "internal error: a column slab needs a single four-step radix-256 pass");
+    a.out_pitch_shift = g_slab.out_pitch_shift;
+    a.out_seg_shift = g_slab.out_seg_shift;
+    a.out_seg_gap = g_slab.out_seg_gap;
+    a.out_col0 = g_slab.col_first;
+    a.out_base = g_slab.out_base;
+  }
 #ifdef TFFT_DEBUG_KERNELS
   a.wg_times = nullptr;
   if (debug_variants_enabled())          // measurement hook of tools/exp_wg_end_times.py
@@ -798,9 +831,13 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   // group's stage 2 split over waves on different SIMDs). Variant bit 1073741824 keeps the throughput kernels (A/B, tuner).
   // Device time per execution, latency / throughput kernels (profiles/r5_small_scan.txt): 2^16 x 1: 8.8 / 14.3 us, x 16: 13.1 /
   // 16.3; 2^18 x 1 as 256 x 256 x 4: 12.8 / 18.1; 2^20 x 1: 18.4 / 22.2. Beyond 64 blocks the sign depends on the pass (2^16 x 32:
-  // 20.0 / 17.7, 2^21 x 1: 26.0 / 28.7, 2^17 x 32: 26.7 / 23.3): the throughput kernels keep everything from there on.
+  // 20.0 / 17.7, 2^21 x 1: 26.0 / 28.7, 2^17 x 32: 26.7 / 23.3): the throughput kernels keep everything from there on. 128 blocks
+  // still win by 7-9 % wherever a row is at least 512 columns wide (2^21 x 1, 2^20 x 2: 26.5 / 28.6, 2^19 x 4: 26.1 / 28.0, 2^18 x 8
+  // as 256 x 256 x 4: 25.9 / 27.6) and lose 13 % at a pitch of 256 (2^16 x 32, above).
   const uint64_t blocks64 = entries * a.pitch / 64;
-  if (wg_allowed && wg4_ok && tw != colfft::kTwFourStep && !(p->variant & kVarNoLat) && !p->launch_iters && blocks64 <= 64) {
+  // (tfft_plan_opts.launch_iters shapes the grids of the grid-stride kernels; this kernel's grid is one workgroup per block either way,
+  // so a launch shape never changes WHICH kernel runs, and with it the bits: test_launch_shape_never_changes_results)
+  if (wg_allowed && wg4_ok && tw != colfft::kTwFourStep && !(p->variant & kVarNoLat) && blocks64 <= (a.pitch >= 512 ? 128u : 64u)) {
     // Workgroup shape (column groups of 16 per workgroup, waves per column group): stage 2 is bound by instruction issue, so the
     // finer the split the shorter the pass - until the row segments get too narrow for the memory system (32-byte segments over
     // 4 MiB: loads land after 2.3 us instead of 0.9, tools/lat_probe). One box, device time per transform, shapes 4 x 2 / 2 x 2 /
@@ -1046,7 +1083,8 @@ int check_variant(uint64_t n, uint64_t inner, int variant) {
 extern "C" {
 
 const char* tfft_last_error(void) { return g_err.c_str(); }
-const char* tfft_version(void) { return "tfft 0.1 (gfx950)"; }
+const char* tfft_version(void) { return "tfft 0.5 (gfx950, ABI 2)"; }
+int tfft_abi_version(void) { return TFFT_ABI_VERSION; }
 
 int tfft_ref_create_plan(uint64_t n, int mode, int base_wpb, int r16_wpb, int r2_bs, tfft_ref_plan* out) {
   g_err.clear();

@@ -114,7 +114,7 @@ class HipEngine:
         except self.capi.TfftError:
             return None
 
-    def dist_plan(self, n, world, rank, comm=None, self_via_comm=False):
+    def dist_plan(self, n, world, rank, comm=None, self_via_comm=False, slabs=1):
         """tfft_dist_plan for this rank with torch-owned exchange and output buffers. Returns (plan, send_re, send_im,
         recv_re, recv_im, out_re, out_im); at world size 1 the receive buffers are the send buffers (unless the own chunk
         is routed through the communicator, a test aid)."""
@@ -126,7 +126,7 @@ class HipEngine:
         send_re, send_im = mk(), mk()
         recv_re, recv_im = (mk(), mk()) if (world > 1 or self_via_comm) else (send_re, send_im)
         plan = self.capi.DistPlan(n, world, rank, self.device, comm=comm, buffers=(send_re, send_im, recv_re, recv_im),
-                                  self_via_comm=self_via_comm)
+                                  self_via_comm=self_via_comm, slabs=slabs)
         return plan, send_re, send_im, recv_re, recv_im, mk(), mk()
 
 
@@ -138,8 +138,9 @@ class DistSetupError(RuntimeError):
 
 class DistributedFFT1D:
     def __init__(self, n, group=None, engine=None, input_layout="columns", output_layout="transposed", fused=None,
-                 transport=None, self_via_comm=False):
-        """transport (GPU engine, fused form, more than one rank): "rccl" = the C ABI runs the exchange itself over a
+                 transport=None, self_via_comm=False, slabs=1):
+        """slabs (1, 2 or 4; "rccl" transport): the exchange overlaps the column pass slab by slab (TFFT_DIST_SLABS_*, include/tfft.h).
+        transport (GPU engine, fused form, more than one rank): "rccl" = the C ABI runs the exchange itself over a
         communicator created through it (default when the process group's backend is nccl); "torch" = this class runs it
         over torch.distributed on the plan's buffers (default otherwise). self_via_comm (with "rccl"): the own chunk goes
         through ncclSend / ncclRecv too, so that a single GPU exercises the collective path (tests)."""
@@ -208,7 +209,7 @@ class DistributedFFT1D:
                 why = self._agree(why, "creating the RCCL communicator")
                 if why is None:
                     try:
-                        self._core = engine.dist_plan(n, p, self.rank, comm=self._comm, self_via_comm=self._via)
+                        self._core = engine.dist_plan(n, p, self.rank, comm=self._comm, self_via_comm=self._via, slabs=slabs)
                         self.geometry = self._core[0].geometry
                     except Exception as e:      # noqa: BLE001
                         why = f"{type(e).__name__}: {e}"

@@ -380,7 +380,9 @@ def test_radix512_column_pass(tf, torch, orc, lg, batch):
     rng = np.random.default_rng(lg + batch)
     re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
     im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
-    multi = 16777216 if lg <= 15 else 0          # 2^13..2^15 default to the single-pass kernel: ask for the column plan
+    # 2^13..2^15 default to the single-pass kernel: ask for the column plan; from 2^16 on name a (neutral) cache-policy bit, so that
+    # the large-batch split is what runs (a variant-0 plan of a few transforms takes the small-work split, tfft_plan_default_variant)
+    multi = 16777216 if lg <= 15 else 536870912
     plan = tf.TfftPlan(n, batch, 0, variant=multi)
     no512 = multi | 8388608 | 33554432           # (without the radix-1024 pass either, which would stand in at 2^18)
     other = tf.TfftPlan(n, batch, 0, variant=no512)

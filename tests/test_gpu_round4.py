@@ -403,7 +403,7 @@ def test_c_abi_spectral_filter_example():
 
 
 @pytest.mark.parametrize("lg,batch,order", [(18, 32, "natural"), (19, 12, "natural"), (20, 16, "natural"), (21, 8, "natural"),
-                                            (22, 4, "natural"), (24, 1, "natural"), (17, 8, "natural"),
+                                            (22, 4, "natural"), (24, 1, "natural"), (17, 32, "natural"),
                                             (20, 16, "transposed"), (22, 4, "transposed"), (24, 1, "transposed"),
                                             (20, 16, "transposed_in")])
 def test_cache_policy_changes_the_time_never_the_result(tf, lg, batch, order):
@@ -415,6 +415,8 @@ def test_cache_policy_changes_the_time_never_the_result(tf, lg, batch, order):
     x = torch.empty(batch * 2 * n, dtype=torch.float16, device="cuda")
     tf.synth_uniform(x, x[n:], n, batch)
     kw = {"natural": {}, "transposed": {"output_order": "transposed"}, "transposed_in": {"input_order": "transposed"}}[order]
+    if order == "natural" and tf.plan_default_variant(n, 1, batch):
+        pytest.skip("variant 0 of this shape is another split (tfft_plan_default_variant), not another cache policy of the same plan")
     outs = []
     for v in (0, 262144, 536870912):
         plan = tf.TfftPlan(n, batch, 0, variant=v, preserve_input=True, **kw)

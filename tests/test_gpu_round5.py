@@ -100,3 +100,130 @@ def test_latency_kernel_many_blocks_and_strided_axis(tf, orc):
     err = np.linalg.norm((got[:, 0] + 1j * got[:, 1]) - ref) / np.linalg.norm(ref)
     assert err <= REL_L2_TOL, err
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the exchange of a distributed transform overlapped with its column pass, slab by slab (TFFT_DIST_SLABS_*)
+# ---------------------------------------------------------------------------------------------------------------------
+def _all_ranks(torch, capi, xr, xi, world, slabs):
+    """All `world` ranks of one transform as plans in this process (comm = NULL), the exchange emulated by device copies of whole
+    chunks (a peer's chunk is one contiguous block for every number of slabs): returns every rank's output planes."""
+    n = xr.size
+    plans = [capi.DistPlan(n, world, r, 0, slabs=slabs) for r in range(world)]
+    g = plans[0].geometry
+    assert int(g.slabs) == slabs
+    n1, n2, c, chunk = int(g.n1), int(g.n2), int(g.cols), int(g.chunk)
+    loc = n // world
+    mk = lambda: torch.full((loc,), float("nan"), dtype=torch.float16, device="cuda")      # noqa: E731
+    bufs = []
+    for p in plans:
+        s_re, s_im = mk(), mk()
+        b = (s_re, s_im, mk(), mk()) if world > 1 else (s_re, s_im, s_re, s_im)
+        p.set_buffers(*b)
+        bufs.append(b)
+    x2r, x2i = xr.reshape(n1, n2), xi.reshape(n1, n2)
+    for r, p in enumerate(plans):
+        p.pre(torch.from_numpy(np.ascontiguousarray(x2r[:, r * c:(r + 1) * c]).reshape(-1)).cuda(),
+              torch.from_numpy(np.ascontiguousarray(x2i[:, r * c:(r + 1) * c]).reshape(-1)).cuda())
+    torch.cuda.synchronize()
+    if world > 1:
+        for q in range(world):
+            for pp in range(world):
+                bufs[q][2][pp * chunk:(pp + 1) * chunk].copy_(bufs[pp][0][q * chunk:(q + 1) * chunk])
+                bufs[q][3][pp * chunk:(pp + 1) * chunk].copy_(bufs[pp][1][q * chunk:(q + 1) * chunk])
+    outs = []
+    for p in plans:
+        o_re, o_im = mk(), mk()
+        p.post(o_re, o_im)
+        torch.cuda.synchronize()
+        outs.append((o_re.clone(), o_im.clone()))
+    for p in plans:
+        p.close()
+    return outs, g
+
+
+@pytest.mark.parametrize("lg,world", [(24, 2), (24, 4), (26, 8), (25, 1)])
+def test_column_slabs_give_the_same_bits_as_one_slab(tf, orc, lg, world):
+    """S = 2 and S = 4 slabs against S = 1, all ranks of the transform in one process: every rank's output bit for bit (the slabs
+    only cut the column pass's launch and re-lay the exchange buffers), and rank 0 / the last rank against the fp64 oracle at the
+    smaller sizes."""
+    import torch
+    from tensor_fft_amd import capi
+
+    n = 1 << lg
+    xr, xi = orc.synth_uniform(n, 1, 0, 900 + lg)
+    base, g = _all_ranks(torch, capi, xr[0], xi[0], world, 1)
+    assert (int(g.n1), int(g.reorder)) == (256, 0)
+    for slabs in (2, 4):
+        outs, _ = _all_ranks(torch, capi, xr[0], xi[0], world, slabs)
+        for r in range(world):
+            assert bool((outs[r][0].view(torch.int16) == base[r][0].view(torch.int16)).all()), (slabs, r)
+            assert bool((outs[r][1].view(torch.int16) == base[r][1].view(torch.int16)).all()), (slabs, r)
+    if lg <= 24:
+        e_re, e_im = orc.dft64(xr, xi)
+        exact = e_re[0] + 1j * e_im[0]
+        n1, n2, k = int(g.n1), int(g.n2), int(g.rows)
+        for r in (0, world - 1):
+            got = base[r][0].cpu().numpy().astype(np.float64) + 1j * base[r][1].cpu().numpy().astype(np.float64)
+            k1 = r * k + np.arange(k)[:, None]
+            want = exact[(k1 + n1 * np.arange(n2)[None, :]).reshape(-1)]
+            assert np.linalg.norm(got - want) / np.linalg.norm(want) < REL_L2_TOL
+
+
+def test_column_slabs_are_refused_where_the_geometry_cannot_overlap(tf):
+    from tensor_fft_amd import capi
+
+    with pytest.raises(tf.TfftError, match="SLABS"):
+        capi.DistPlan(1 << 20, 2, 0, 0, slabs=2)          # 256 x 4096: the row transforms are single kernels behind a re-order pass
+    with pytest.raises(tf.TfftError, match="SLABS"):
+        capi.DistPlan(1 << 21, 8, 0, 0, slabs=4)          # 512 x 4096: the column pass is radix 512
+
+
+def test_overlapped_exchange_through_a_real_communicator(tf):
+    """World 1 with the own chunk through ncclSend / ncclRecv (TFFT_DIST_SELF_VIA_COMM), S = 1, 2, 4 through tfft_dist_exec: with
+    S > 1 the exchange runs on the plan's second stream behind per-slab events. Same bits for every S, correct against numpy, and
+    the overlapped transform is not slower than column pass + exchange one after the other."""
+    import subprocess
+
+    code = r'''
+import numpy as np, torch, time
+import __graft_entry__ as g
+g.build()
+from tensor_fft_amd.distributed import DistributedFFT1D, HipEngine
+n = 1 << 26
+rng = np.random.default_rng(5)
+xr, xi = rng.uniform(-1, 1, n).astype(np.float16), rng.uniform(-1, 1, n).astype(np.float16)
+exact = np.fft.fft(xr.astype(np.float64) + 1j * xi.astype(np.float64)) / n
+ref = None
+for slabs in (1, 2, 4):
+    f = DistributedFFT1D(n, engine=HipEngine(0), transport="rccl", self_via_comm=True, slabs=slabs)
+    assert f.geometry.slabs == slabs
+    idx = f.input_indices()
+    a, b = torch.from_numpy(xr[idx].copy()).cuda(), torch.from_numpy(xi[idx].copy()).cuda()
+    for _ in range(3):
+        re, im = f.forward(a, b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        re, im = f.forward(a, b)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    ph = f.phase_times(a, b, 10)
+    got = re.cpu().numpy().astype(np.float64) + 1j * im.cpu().numpy().astype(np.float64)
+    want = exact[f.output_indices()]
+    rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    assert rel < 1.5e-3, rel
+    if ref is None:
+        ref = (re.clone(), im.clone())
+    else:
+        assert bool((re.view(torch.int16) == ref[0].view(torch.int16)).all()) and bool((im.view(torch.int16) == ref[1].view(torch.int16)).all())
+    print("slabs %d: %.3f ms per transform; phases one after the other: pre %.3f + exchange %.3f + post %.3f = %.3f ms; rel-L2 %.2e"
+          % (slabs, ms, ph["pre_ms"], ph["exchange_ms"], ph["post_ms"], ph["pre_ms"] + ph["exchange_ms"] + ph["post_ms"], rel))
+    if slabs > 1:
+        assert ms < (ph["pre_ms"] + ph["exchange_ms"] + ph["post_ms"]) * 1.02, "the overlapped transform is slower than its phases in a row"
+    f.close()
+print("SLABS-OK")
+'''
+    r = subprocess.run(["timeout", "-k", "10", "300", "python3", "-c", code], cwd=ROOT, capture_output=True, text=True)
+    print(r.stdout[-4000:], r.stderr[-4000:])
+    assert r.returncode == 0 and "SLABS-OK" in r.stdout, r.stdout + r.stderr

@@ -186,7 +186,7 @@ class Engine:
     capi, device = FakeCapi, 0
     def supports_fourstep(self, n1, inner): return True
     def dist_geometry(self, n, world, rank): return Geo()
-    def dist_plan(self, n, world, rank, comm=None, self_via_comm=False):
+    def dist_plan(self, n, world, rank, comm=None, self_via_comm=False, slabs=1):
         if %(fail_plan_rank)d == rank: raise RuntimeError("hipMalloc(distributed plan buffers): out of memory")
         return (Plan(), None, None, None, None, None, None)
 try:
@@ -265,6 +265,7 @@ def test_bench_side_entries_share_one_failure_policy(monkeypatch, capsys):
         cuda = FakeTorch.cuda
 
     out = bench.other_configs(T, FakeTf, None, 0)
-    assert len(out) == 13 and all("error" in v and "stub" in v["error"] for v in out.values()), out
-    assert len(calls) == 13                                        # every entry was attempted
+    assert len(out) == 14 and all("error" in v and "stub" in v["error"] for v in out.values()), out
+    assert len(calls) == 14                                        # every entry was attempted (round 5: + reference_protocol_single)
+    assert "reference_protocol_single" in out
     assert "other_configs[configs[3]_2d_4096x4096_x_64]" in capsys.readouterr().err
