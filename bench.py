@@ -451,7 +451,7 @@ def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm
         why = str(e)
         f = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="torch")
     try:
-        return _dist_2pow26_body(torch, tf, dist, rank, world, f, n, why, want_native, self_via_comm, reps, capi)
+        return _dist_2pow26_body(torch, tf, dist, rank, world, f, n, why, want_native, self_via_comm, reps, capi, local_rank)
     finally:
         f.close()          # the plan, its 512 MiB of buffers and the communicator go whatever happened above
 
@@ -466,8 +466,9 @@ def _agree(torch, dist, world, ok_local):
     return bool(int(t[0]))
 
 
-def _dist_2pow26_body(torch, tf, dist, rank, world, f, n, why, want_native, self_via_comm, reps, capi):
+def _dist_2pow26_body(torch, tf, dist, rank, world, f, n, why, want_native, self_via_comm, reps, capi, local_rank):
     import numpy as np
+    from tensor_fft_amd.distributed import DistributedFFT1D, HipEngine
 
     g = f.geometry
     n1, n2, c, k = int(g.n1), int(g.n2), int(g.cols), int(g.rows)
@@ -563,6 +564,41 @@ def _dist_2pow26_body(torch, tf, dist, rank, world, f, n, why, want_native, self
         return report
     report["check"] = (f"Parseval over all ranks + 4 bins of every rank's own slice against a direct fp64 DFT sum on the device: max |delta| "
                        f"over the ranks {worst:.2e} (spectrum rms {rms:.2e})")
+    # ---- the same transform with the exchange overlapped slab by slab (TFFT_DIST_SLABS_*): whole-transform time for S = 2 and 4 beside
+    # the S = 1 figure above (whose three phases are separable because they run one after the other); every S must give S = 1's bits
+    if f.transport == "rccl" and want_native:
+        over = {}
+        for slabs in (2, 4):
+            err_s, ms_s, same = None, 0.0, False
+            f2 = None
+            try:
+                f2 = DistributedFFT1D(n, engine=HipEngine(local_rank), transport="rccl", self_via_comm=self_via_comm, slabs=slabs)
+                for _ in range(3):
+                    r2, i2 = f2.forward(in_re, in_im)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    r2, i2 = f2.forward(in_re, in_im)
+                fence()
+                ms_s = (time.perf_counter() - t0) / reps * 1e3
+                same = bool((r2.view(torch.int16) == re.view(torch.int16)).all()) and bool((i2.view(torch.int16) == im.view(torch.int16)).all())
+            except Exception as e:      # noqa: BLE001  (a refused geometry is refused on every rank alike; a setup failure is agreed inside the constructor)
+                err_s = f"{type(e).__name__}: {e}"
+            finally:
+                if f2 is not None:
+                    f2.close()
+            if not _agree(torch, dist, world, err_s is None):
+                over[f"slabs_{slabs}"] = {"error": err_s or "another rank failed"}
+                break
+            t = torch.tensor([ms_s, 1.0 if same else 0.0], dtype=torch.float64, device="cuda")
+            tmin = t.clone()
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            over[f"slabs_{slabs}"] = {"ms": float(t[0]), "gsamples_per_s": n / float(t[0]) / 1e6, "bit_identical_to_one_slab_on_every_rank": bool(float(tmin[1]))}
+            if not bool(float(tmin[1])):
+                report["error"] = f"self-check failed: {slabs} column slabs do not reproduce the bits of one slab"
+        report["overlapped_exchange"] = over
     return report
 
 

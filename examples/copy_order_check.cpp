@@ -4,9 +4,10 @@
 // hipMemcpy; the library's pinned ring, tfft_copy_h2d) are driven with a long queue of transforms in front of the copy:
 // the LAST queued transform must still see signal A. exit 0 / 1.
 //
-// usage: copy_order_check [log2_N = 16] [queued transforms = 2000]   (a length whose plan leaves the input block intact: an even
-// number of passes, 2^16 for a single transform; the odd-pass lengths - a single 2^17 .. 2^21 takes three since round 5,
-// tfft_plan_default_variant - use it as scratch, the reference's contract, ComputeFFT.h:89-93)
+// usage: copy_order_check [log2_N = 14] [queued transforms = 2000]   (a length whose transform leaves the input block intact: the
+// result must land in the RESULTS half - Plan::results_in_results_, Plan.h:109-115: 2^12, 2^14, 2^17 ... - and the plan must not use
+// the input as scratch: a single kernel (to 2^15) or an even number of passes. A single 2^17 .. 2^21 takes three passes since round
+// 5, tfft_plan_default_variant, and uses the input block as scratch, the reference's contract, ComputeFFT.h:89-93.)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,7 +16,7 @@
 #include "tensor_fft.hpp"
 
 int main(int argc, char** argv) {
-  const int lg = argc > 1 ? std::atoi(argv[1]) : 16;
+  const int lg = argc > 1 ? std::atoi(argv[1]) : 14;
   const int queued = argc > 2 ? std::atoi(argv[2]) : 2000;
   const int n = 1 << lg;
   auto maybe_plan = CreatePlan(n, Mode_4096, 16, 1, 256);

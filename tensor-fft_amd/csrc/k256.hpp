@@ -60,6 +60,15 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
   const uint32_t in_lane = 8 * (lane & 31);
   // output: lane (k1 = x, g) writes k = 4g..4g+3 + 16 k1: halves 16 x + 4 g
   const uint32_t out_lane = 16 * x + 4 * g;
+  // Staging position of that 8-byte piece inside the plane's 512-byte image. Plain (byte 32 x + 8 g) the 16 lanes of a
+  // ds_write_b64 group sit 32 bytes apart: x, x + 4, x + 8, x + 12 on one bank, 4-way (round 5 PMC: SQ_LDS_BANK_CONFLICT = 60 % of
+  // the LDS-active cycles of this kernel, profiles/r5_n256_pmc_summary.json). The 16-byte half of the unit is flipped with bit 2 of
+  // x and the 8-byte half inside it with bit 3: four different banks; the read-out below undoes both.
+#ifdef TFFT_K256_PLAIN_STAGE       // A/B knob: the layout of rounds 1-4
+  const uint32_t stage_off = 2 * out_lane;
+#else
+  const uint32_t stage_off = 32u * x + 16u * ((g >> 1) ^ ((x >> 2) & 1)) + 8u * ((g & 1) ^ ((x >> 3) & 1));
+#endif
 
   const uint32_t groups = (batch + kFftsPerWave - 1) / kFftsPerWave;
   for (uint32_t grp = blockIdx.x * kWavesPerBlock + wave; grp < groups; grp += gridDim.x * kWavesPerBlock) {
@@ -119,16 +128,24 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
       // stage the spectrum in the transform's own (consumed) 1-KiB slot [RE 512 B | IM 512 B] ...
       const u2 vr = {pk(o_re[0], o_re[1]), pk(o_re[2], o_re[3])};
       const u2 vi = {pk(o_im[0], o_im[1]), pk(o_im[2], o_im[3])};
-      *reinterpret_cast<u2*>(wl + t * 1024 + 2 * out_lane) = vr;
-      *reinterpret_cast<u2*>(wl + t * 1024 + 512 + 2 * out_lane) = vi;
+      *reinterpret_cast<u2*>(wl + t * 1024 + stage_off) = vr;
+      *reinterpret_cast<u2*>(wl + t * 1024 + 512 + stage_off) = vi;
     }
     // ... and store it as one 1-KiB row per transform: lanes 0-31 the RE plane, lanes 32-63 the IM plane, 16-byte
     // non-temporal stores (+2-4 % over 8-byte pieces straight from registers)
 #pragma unroll
     for (int t = 0; t < kFftsPerWave; ++t) {
-      const u4 v = *reinterpret_cast<const u4*>(wl + t * 1024 + 16 * lane);
+      u4 v = *reinterpret_cast<const u4*>(wl + t * 1024 + 16 * lane);
+#ifdef TFFT_K256_PLAIN_STAGE
+      const uint32_t chunk = lane & 31;
+#else
+      // lane l of a plane holds unit x = l >> 1: the 16-byte halves of the unit trade places where bit 2 of x is set, the 8-byte
+      // halves inside where bit 3 is
+      const uint32_t chunk = (lane & 31) ^ ((lane >> 3) & 1);
+      if ((lane >> 4) & 1) v = u4{v.z, v.w, v.x, v.y};
+#endif
       if (static_cast<uint32_t>(t) < nb) {
-        uint16_t* dst = ((lane < 32) ? out_re : out_im) + out_map.off(b0 + t) + 8 * (lane & 31);
+        uint16_t* dst = ((lane < 32) ? out_re : out_im) + out_map.off(b0 + t) + 8 * chunk;
         if (OTW) *reinterpret_cast<u4*>(dst) = v;      // intermediate of a transposed-input plan: stays in the Infinity Cache for the column pass
         else __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
       }

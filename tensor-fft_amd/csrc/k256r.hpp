@@ -150,6 +150,13 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
   }
   // output: lane (k1 = x, g) writes kk = 4 g .. 4 g + 3 + 16 k1 of every segment s: halves 256 s + 16 x + 4 g
   const uint32_t out_lane = 16 * x + 4 * g;
+  // staging position of that 8-byte piece inside a segment's 512 bytes, bank-conflict free (k256.hpp: plain, 32 x + 8 g, the 16
+  // lanes of a ds_write_b64 group collide 4-way: 56 % of this kernel's LDS-active cycles, profiles/r5_n1024_pmc_summary.json)
+#ifdef TFFT_K256_PLAIN_STAGE       // A/B knob: the layout of rounds 1-4
+  const uint32_t stage_off = 2 * out_lane;
+#else
+  const uint32_t stage_off = 32u * x + 16u * ((g >> 1) ^ ((x >> 2) & 1)) + 8u * ((g & 1) ^ ((x >> 3) & 1));
+#endif
 
   const uint32_t groups = (batch + kPerWave - 1) / kPerWave;
   for (uint32_t grp = blockIdx.x * kWavesPerBlock + wave; grp < groups; grp += gridDim.x * kWavesPerBlock) {
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
       }
       if (STG) {
         // the transposed reads of transform t have all returned (their data went through the MFMAs above)
-        uint8_t* const slot = wl + t * 2 * kPlane + 2 * out_lane;
+        uint8_t* const slot = wl + t * 2 * kPlane + stage_off;
 #pragma unroll
         for (int s = 0; s < R; ++s) {
           *reinterpret_cast<u2*>(slot + 512 * s) = u2{pk_re[s][0], pk_re[s][1]};
@@ -289,9 +296,15 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int t = i / R, ii = i % R, plane = ii / (R / 2), pq = ii % (R / 2);
-        const u4 v = *reinterpret_cast<const u4*>(wl + i * 1024 + 16 * lane);
+        u4 v = *reinterpret_cast<const u4*>(wl + i * 1024 + 16 * lane);
+#ifdef TFFT_K256_PLAIN_STAGE
+        const uint32_t chunk = lane;
+#else
+        const uint32_t chunk = lane ^ ((lane >> 3) & 1);          // (two 512-byte segments per piece; the swizzle is per segment)
+        if ((lane >> 4) & 1) v = u4{v.z, v.w, v.x, v.y};
+#endif
         if (static_cast<uint32_t>(t) < nb) {
-          uint16_t* dst = (plane ? out_im : out_re) + out_map.off(b0 + t) + 512 * pq + 8 * lane;
+          uint16_t* dst = (plane ? out_im : out_re) + out_map.off(b0 + t) + 512 * pq + 8 * chunk;
           if (OTW) *reinterpret_cast<u4*>(dst) = v;      // intermediate of a transposed-input plan (see k256.hpp)
           else __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
         }

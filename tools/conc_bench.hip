@@ -68,12 +68,24 @@ void run(const uint8_t* in, uint8_t* out, uint64_t pitch, uint64_t plane_bytes, 
          wg_per_cu, grid, W * wg_per_cu, grid / wg_per_cu > 256 ? 256 : grid / wg_per_cu, ms * 1e3, 4.0 * total * TILE / ms * 1e-6);
 }
 
-int main() {
+int main(int argc, char** argv) {
   const uint64_t plane = 1ull << 30;
   uint8_t *in, *out;
   hipMalloc(&in, 2 * plane);
   hipMalloc(&out, 2 * plane);
   hipMemset(in, 1, 2 * plane);
+  if (argc > 1) {
+    // round 5: conc_bench PITCH_BYTES = the copy ceiling of a radix-512 / radix-1024 column pass with that row pitch (64-column
+    // tiles of 512 or 1024 rows, one 8-wave workgroup per CU, static partition and two generations: what the library launches)
+    const uint64_t pitch_arg = std::strtoull(argv[1], nullptr, 0);
+    printf("row pitch %llu B, planes 1 GiB apart, 2 GiB moved per launch\n", (unsigned long long)pitch_arg);
+    for (int grid : {256, 512}) {
+      run<128, 8, 65536>(in, out, pitch_arg, plane, 1, grid);      // 512 rows x 128 B
+      run<128, 8, 131072>(in, out, pitch_arg, plane, 1, grid);     // 1024 rows x 128 B
+      run<256, 8, 65536>(in, out, pitch_arg, plane, 1, grid);      // 256 rows x 256 B
+    }
+    return 0;
+  }
   const uint64_t pitch = 8192;
   printf("row pitch %llu B, planes 1 GiB apart, 2 GiB moved per launch\n", (unsigned long long)pitch);
   for (int grid : {128, 192, 256}) {
