@@ -141,6 +141,9 @@ typedef struct tfft_plan_opts {
                            by the plan's footprint, see tfft_plan_cache_policy(); 1048576 = 16-byte stores straight from
                            registers,
                            4096 / 8192 = per-wave kernel with LDS-staged stores / hardware sin-cos twiddles.
+                           1073741824 = never the latency form of the radix-256 column pass (collat.hpp: one 64-column
+                           block per workgroup of 4 or 8 waves, chosen for passes of at most 64 / 128 blocks): keep the
+                           throughput kernels for such passes too (same accuracy bound; the twiddles round differently).
                            Unknown bits are rejected (TFFT_ERR_ARG), see tfft_variant_check().
                            Timing / debugging aids that give WRONG or partial results are NOT part of this field's
                            accepted values: 4 and 64 (N == 4096 kernel: fake stores / no compute), (p << 8), p = 1..15 (run
@@ -224,11 +227,15 @@ uint64_t tfft_plan_transposed_n2(uint64_t n);
  * profiles/r4_cache_policy.txt. The results do not depend on the policy, only the time does. */
 int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch);
 
-/* Host only. The planner bits tfft_plan_create gives a NATURAL-order plan whose caller left `variant` at 0: 0 when the work
- * (n * batch samples) fills the chip - the splits behind variant 0 were measured at 2^30 samples per launch - and otherwise
- * the bits of the split with more, smaller workgroups (a single 2^20-point transform is 16 workgroups of the radix-1024 kernel
- * on 256 CUs: 40 us; as 256 x 256 x 16 it takes 24 us). 2^17 ... 2^21, two 2^24 and a single 2^25 only; measured limits:
- * profiles/r4_small_batch_scan.txt.
+/* Host only. The planner bits tfft_plan_create gives a NATURAL-order plan whose caller left `variant` at 0. In this order:
+ * (1) a wisdom line for (n, nearest batch within three octaves), see tfft_tuning_load() below; (2) 0 when the work (n * batch
+ * samples) fills the chip - the splits behind variant 0 were measured at 2^30 samples per launch; (3) otherwise the bits of the
+ * split with more, smaller workgroups (a single 2^20-point transform is 16 workgroups of the radix-1024 kernel on 256 CUs: 40 us;
+ * as 256 x 256 x 16 with the latency column kernel it takes 18 us): 2^17 ... 2^21 up to 2^20 (2^17, 2^18) / 2^22 (2^19 ... 2^21)
+ * samples per launch; 2^18 up to 2^22 samples: the other radix-512 kernel. Measured limits: profiles/r5_small_scan.txt. The
+ * within-noise rules of round 4 (two 2^24, a single 2^25) are wisdom lines now (profiles/r5_TunerResults.dat), not code.
+ * Independent of the variant, radix-256 column passes of at most 64 blocks (128 from a row pitch of 512 columns on) run as the
+ * latency kernel (collat.hpp) unless the variant holds 1073741824.
  * tfft_plan_describe(n, inner, tfft_plan_default_variant(n, inner, batch), ...) is the decomposition such a plan gets. A caller
  * that names any variant bit itself gets exactly that variant. */
 int tfft_plan_default_variant(uint64_t n, uint64_t inner, uint64_t batch);

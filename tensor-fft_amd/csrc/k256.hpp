@@ -64,7 +64,10 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
   // ds_write_b64 group sit 32 bytes apart: x, x + 4, x + 8, x + 12 on one bank, 4-way (round 5 PMC: SQ_LDS_BANK_CONFLICT = 60 % of
   // the LDS-active cycles of this kernel, profiles/r5_n256_pmc_summary.json). The 16-byte half of the unit is flipped with bit 2 of
   // x and the 8-byte half inside it with bit 3: four different banks; the read-out below undoes both.
-#ifdef TFFT_K256_PLAIN_STAGE       // A/B knob: the layout of rounds 1-4
+  // Measured in one process (profiles/r5_ab_k256_stage.txt): the conflicts go, the kernel gets 1.1 % SLOWER here (354.2 against
+  // 350.3 us per 2^31 bytes: the extra read-out swap costs more than the conflicts did under the memory wait), while k256r.hpp
+  // gains 0.3-0.6 % from the same layout and keeps it. So this kernel stays on the plain layout; the knob keeps the experiment.
+#ifndef TFFT_K256_SWIZZLED_STAGE
   const uint32_t stage_off = 2 * out_lane;
 #else
   const uint32_t stage_off = 32u * x + 16u * ((g >> 1) ^ ((x >> 2) & 1)) + 8u * ((g & 1) ^ ((x >> 3) & 1));
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
 #pragma unroll
     for (int t = 0; t < kFftsPerWave; ++t) {
       u4 v = *reinterpret_cast<const u4*>(wl + t * 1024 + 16 * lane);
-#ifdef TFFT_K256_PLAIN_STAGE
+#ifndef TFFT_K256_SWIZZLED_STAGE
       const uint32_t chunk = lane & 31;
 #else
       // lane l of a plane holds unit x = l >> 1: the 16-byte halves of the unit trade places where bit 2 of x is set, the 8-byte

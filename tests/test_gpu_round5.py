@@ -250,3 +250,18 @@ print("SLABS-OK")
     r = subprocess.run(["timeout", "-k", "10", "300", "python3", "-c", code], cwd=ROOT, capture_output=True, text=True)
     print(r.stdout[-4000:], r.stderr[-4000:])
     assert r.returncode == 0 and "SLABS-OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("lg,order", [(20, "transposed"), (21, "transposed")])
+def test_mfma_flops_are_linear_in_the_batch_across_the_chunk_boundary(tf, lg, order):
+    """tfft_plan_mfma_flops of a chunked plan (sub-plans built for ONE chunk, run batch / chunk times plus a tail pair): the same
+    flops per transform below one chunk, at whole multiples and with a ragged tail, and equal to the unchunked natural-order plan's
+    count where both run the same kernels' MFMA stages."""
+    per = []
+    for batch in (1, 64, 128, 256, 300, 513):
+        plan = tf.TfftPlan(1 << lg, batch, 0, output_order=order)
+        f = plan.mfma_flops
+        assert f > 0
+        per.append(f / batch)
+        plan.close()
+    assert max(per) - min(per) <= 1e-9 * max(per), per
