@@ -31,12 +31,15 @@
 // bit-identical to them (hardware sin / cos twiddles, |error| ~ 1e-6, instead of the two-level fp32 tables).
 #pragma once
 
+#include <type_traits>
+
 #include "colfft.hpp"
 
 namespace colfft {
 
-// CG column groups of 16 columns per workgroup, HH waves per column group
-template <int CG, int HH>
+// CG column groups of 16 columns per workgroup, HH waves per column group, PP workgroups per block (each takes 16 / PP of every
+// column group's stage-2 tiles and writes the rows that come out of them)
+template <int CG, int HH, int PP = 1>
 struct LatGeom {
   static constexpr int kThreads = 64 * CG * HH;
   static constexpr int kCols = 16 * CG;
@@ -46,20 +49,26 @@ struct LatGeom {
   static constexpr int kPlane = 256 * kRowBytes;
   static constexpr int kPieces = kPlane / 16 / kThreads;   // 16-byte pieces per thread and plane
   static constexpr int kLds = kLdsTable + 2 * kPlane; // G (16 KiB) + one image
-  static constexpr int kTiles = 16 / HH;              // stage-2 tiles per wave
-  static_assert(CG * HH <= 8 && kPieces >= 1 && (HH == 2 || HH == 4), "shape");
+  static constexpr int kSplit = HH * PP;              // ways a column group's 16 stage-2 tiles are split
+  static constexpr int kTiles = 16 / kSplit;          // stage-2 tiles per wave
+  static_assert(CG * HH <= 8 && kPieces >= 1 && (HH == 2 || HH == 4) && (PP == 1 || PP == 2 || PP == 4) && kTiles >= 2, "shape");
 };
 
-template <int MODE, int TW, int CG, int HH>
+template <int MODE, int TW, int CG, int HH, int PP = 1>
 __global__ __launch_bounds__(64 * CG * HH, 2) void collat256_kernel(Args a) {
   static_assert(TW == kTwNone || TW == kTwNext, "the latency kernel has no four-step twiddle form");
-  using G = LatGeom<CG, HH>;
+  using G = LatGeom<CG, HH, PP>;
   constexpr int kPlane = G::kPlane, kRps = G::kRps, kCpr = G::kCpr, kT = G::kThreads, kPieces = G::kPieces;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = wave % CG, hh = wave / CG;      // column group of 16 columns; which 16 / HH of its stage-2 tiles
+  const int cg = wave % CG, hh = wave / CG;      // column group of 16 columns; which of its waves
+  // PP > 1: workgroups b, b + nblk, ... share block b (same XCD when nblk is a multiple of 8: the partner's loads hit its L2);
+  // each loads the whole block, runs stage 1 and takes tiles sp = part HH + hh of the kSplit-way split of stage 2
+  const uint32_t nblk = gridDim.x / PP;
+  const int part = PP == 1 ? 0 : __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x / nblk));
+  const int sp = part * HH + hh;
 
   TFFT_WG_STAMP(a, 0);
   uint8_t* const img = lds + kLdsTable;
@@ -93,9 +102,9 @@ __global__ __launch_bounds__(64 * CG * HH, 2) void collat256_kernel(Args a) {
       raw_im[i] = *reinterpret_cast<const u4*>(reinterpret_cast<const uint8_t*>(a.in_im + bidx * a.in_stride) + off);
     }
   };
-  // ---- next pass's input twiddle on output k = ka + 16 kb of a column: w = base[r] step^(ka - kTiles hh), E = a (kprev + ns k) mod T
+  // ---- next pass's input twiddle on output k = ka + 16 kb of a column: w = base[r] step^(ka - kTiles sp), E = a (kprev + ns k) mod T
   // exactly as in colfft256_wg_kernel, with v_sin / v_cos (revolutions) in place of the table look-ups and the wave's first tile
-  // (ka = kTiles hh) folded into the base
+  // (ka = kTiles sp) folded into the base
   cpx base[4], step = {1.f, 0.f};
   auto twiddle_setup = [&](uint32_t blk_in) {
     if (TW != kTwNext) return;
@@ -110,13 +119,13 @@ __global__ __launch_bounds__(64 * CG * HH, 2) void collat256_kernel(Args a) {
       const uint32_t kb = (MODE == kColsOnLanes) ? (4 * g + r) : x;
       const uint64_t kprev = (MODE == kColsOnLanes) ? (((m0 + x) - (rest_l << a.ns_f_shift)) >> a.inner_shift)
                                                     : ((kprev_f0 + 4 * g + r) >> a.inner_shift);
-      base[r] = lookup<false>(a, (av * ((kprev + a.ns * (16 * kb + G::kTiles * hh)) & a.t_mask)) & a.t_mask);
+      base[r] = lookup<false>(a, (av * ((kprev + a.ns * (16 * kb + G::kTiles * sp)) & a.t_mask)) & a.t_mask);
       base[r].re *= a.tw_scale;
       base[r].im *= a.tw_scale;
     }
   };
 
-  Rotor rot(blockIdx.x, gridDim.x);                                      // (block order: k4096::Rotor)
+  Rotor rot(blockIdx.x - part * nblk, nblk);                             // (block order: k4096::Rotor)
   uint32_t blk = rot.item();
   if (blk >= total) return;
   issue_loads(blk);
@@ -179,8 +188,8 @@ __global__ __launch_bounds__(64 * CG * HH, 2) void collat256_kernel(Args a) {
         transpose4(pi[0 + pp][r], pi[2 + pp][r], pi[4 + pp][r], pi[6 + pp][r]);
       }
 
-    // ---- stage 2: this wave's tiles ka = kTiles hh + kk. The register arrays are indexed with compile-time constants only
-    // (a runtime index would send them to scratch), hence one unrolled copy per hh behind a wave-uniform branch.
+    // ---- stage 2: this wave's tiles ka = kTiles sp + kk. The register arrays are indexed with compile-time constants only
+    // (a runtime index would send them to scratch), hence one unrolled copy per sp behind a wave-uniform branch.
     cpx pw = {1.f, 0.f};
     float hold_re[4], hold_im[4];
     uint32_t acc_re[4][4], acc_im[4][4];
@@ -233,41 +242,38 @@ __global__ __launch_bounds__(64 * CG * HH, 2) void collat256_kernel(Args a) {
         }
       }
     };
-    constexpr int kTl = G::kTiles;
-    if (hh == 0) {
+    constexpr int kTl = G::kTiles, kSp = G::kSplit;
+    // the tiles of split index S0, then (columns on lanes) their outputs into the image: column 16 cg + x is image row 16 cg + x
+    // (512 B per column); its outputs k = 16 (4 g + r) + ka are 32 bytes per (g, r), this wave's share of them the 32 / kSplit
+    // bytes at 2 kTl S0: 16-byte chunk c = 2 (4 g + r) + (that offset >> 4) at slot c ^ x
+    auto run_split = [&](auto s0_tag) {
+      constexpr int S0 = decltype(s0_tag)::value;
 #pragma unroll
-      for (int kk = 0; kk < kTl; ++kk) tile2(kk);
-    } else if (hh == 1) {
+      for (int kk = 0; kk < kTl; ++kk) tile2(S0 * kTl + kk);
+      if (MODE == kColsOnLanes) {
+        constexpr int kByte = 2 * kTl * S0;                     // offset inside the 32 bytes of one (g, r)
+        constexpr int j0 = (kByte & 15) / 4;                    // first of the kTl / 2 acc entries ((ka >> 1) & 3) this wave filled
 #pragma unroll
-      for (int kk = 0; kk < kTl; ++kk) tile2(kTl + kk);
-    } else if (HH == 4 && hh == 2) {
-#pragma unroll
-      for (int kk = 0; kk < kTl; ++kk) tile2((HH == 4 ? 2 : 0) * kTl + kk);
-    } else if (HH == 4) {
-#pragma unroll
-      for (int kk = 0; kk < kTl; ++kk) tile2((HH == 4 ? 3 : 0) * kTl + kk);
-    }
-    if (MODE == kColsOnLanes) {
-      // column 16 cg + x: image row 16 cg + x (512 B per column), 16-byte chunk c = 2 (4 g + r) + (ka >> 3) at slot c ^ x.
-      // HH = 2: this wave's 8 tiles are one whole chunk (k = 16 (4 g + r) + 8 hh .. + 7); HH = 4: 4 tiles = one 8-byte half of it
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (HH == 2) {
-          const u4 vr = {acc_re[r][0], acc_re[r][1], acc_re[r][2], acc_re[r][3]};
-          const u4 vi = {acc_im[r][0], acc_im[r][1], acc_im[r][2], acc_im[r][3]};
-          uint8_t* dst = img + 8192 * cg + 512 * x + 16 * ((2 * (4 * g + r) + hh) ^ x);
-          *reinterpret_cast<u4*>(dst) = vr;
-          *reinterpret_cast<u4*>(dst + kPlane) = vi;
-        } else {
-          // (acc[r][j], j = (ka >> 1) & 3: hh even -> j = 0, 1, hh odd -> j = 2, 3)
-          const u2 vr = (hh & 1) ? u2{acc_re[r][2], acc_re[r][3]} : u2{acc_re[r][0], acc_re[r][1]};
-          const u2 vi = (hh & 1) ? u2{acc_im[r][2], acc_im[r][3]} : u2{acc_im[r][0], acc_im[r][1]};
-          uint8_t* dst = img + 8192 * cg + 512 * x + 16 * ((2 * (4 * g + r) + (hh >> 1)) ^ x) + 8 * (hh & 1);
-          *reinterpret_cast<u2*>(dst) = vr;
-          *reinterpret_cast<u2*>(dst + kPlane) = vi;
+        for (int r = 0; r < 4; ++r) {
+          uint8_t* dst = img + 8192 * cg + 512 * x + 16 * ((2 * (4 * g + r) + (kByte >> 4)) ^ x) + (kByte & 15);
+          if (kTl == 8) {
+            *reinterpret_cast<u4*>(dst) = u4{acc_re[r][0], acc_re[r][1], acc_re[r][2], acc_re[r][3]};
+            *reinterpret_cast<u4*>(dst + kPlane) = u4{acc_im[r][0], acc_im[r][1], acc_im[r][2], acc_im[r][3]};
+          } else if (kTl == 4) {
+            *reinterpret_cast<u2*>(dst) = u2{acc_re[r][j0], acc_re[r][j0 + 1]};
+            *reinterpret_cast<u2*>(dst + kPlane) = u2{acc_im[r][j0], acc_im[r][j0 + 1]};
+          } else {
+            *reinterpret_cast<uint32_t*>(dst) = acc_re[r][j0];
+            *reinterpret_cast<uint32_t*>(dst + kPlane) = acc_im[r][j0];
+          }
         }
       }
-    }
+    };
+#define TFFT_LAT_SPLIT(S0) \
+  if (kSp > S0 && sp == S0) run_split(std::integral_constant<int, (S0 < kSp ? S0 : 0)>{});
+    TFFT_LAT_SPLIT(0) TFFT_LAT_SPLIT(1) TFFT_LAT_SPLIT(2) TFFT_LAT_SPLIT(3)
+    TFFT_LAT_SPLIT(4) TFFT_LAT_SPLIT(5) TFFT_LAT_SPLIT(6) TFFT_LAT_SPLIT(7)
+#undef TFFT_LAT_SPLIT
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // C: the output image is complete
     TFFT_WG_STAMP(a, 4);
@@ -277,16 +283,34 @@ __global__ __launch_bounds__(64 * CG * HH, 2) void collat256_kernel(Args a) {
     uint16_t* const o_im = a.out_im + bidx * a.out_stride;
     if (MODE == kColsOnLanes) {
       // the image is the block's output as it lies in memory: 16 CG columns x 512 contiguous bytes per plane, chunk c of column
-      // f (within its group of 16) at slot c ^ f
+      // f (within its group of 16) at slot c ^ f. PP = 2: this workgroup made the chunks of parity `part`; PP = 4: the 8-byte half
+      // part & 1 of the chunks of parity part >> 1
 #pragma unroll
       for (int i = 0; i < kPieces; ++i) {
         const uint32_t col = (kT / 32) * i + (tid >> 5);          // column within the block
         const uint32_t chunk = (tid & 31) ^ (col & 15);
-        const u4 vr = *reinterpret_cast<const u4*>(img + 16 * (kT * i + tid));
-        const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 16 * (kT * i + tid));
         const uint64_t o = (mb + col) * 256 + 8 * chunk;
-        *reinterpret_cast<u4*>(o_re + o) = vr;
-        *reinterpret_cast<u4*>(o_im + o) = vi;
+        if (PP == 1) {
+          const u4 vr = *reinterpret_cast<const u4*>(img + 16 * (kT * i + tid));
+          const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 16 * (kT * i + tid));
+          *reinterpret_cast<u4*>(o_re + o) = vr;
+          *reinterpret_cast<u4*>(o_im + o) = vi;
+        } else if (PP == 2) {
+          if ((chunk & 1) == static_cast<uint32_t>(part)) {
+            const u4 vr = *reinterpret_cast<const u4*>(img + 16 * (kT * i + tid));
+            const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 16 * (kT * i + tid));
+            *reinterpret_cast<u4*>(o_re + o) = vr;
+            *reinterpret_cast<u4*>(o_im + o) = vi;
+          }
+        } else {
+          if ((chunk & 1) == static_cast<uint32_t>(part >> 1)) {
+            const uint32_t hb = 8 * (part & 1);
+            const u2 vr = *reinterpret_cast<const u2*>(img + 16 * (kT * i + tid) + hb);
+            const u2 vi = *reinterpret_cast<const u2*>(img + kPlane + 16 * (kT * i + tid) + hb);
+            *reinterpret_cast<u2*>(o_re + o + hb / 2) = vr;
+            *reinterpret_cast<u2*>(o_im + o + hb / 2) = vi;
+          }
+        }
       }
     } else {
       const uint64_t restb = mb >> a.ns_f_shift;                 // the block's columns share it (ns_f % (16 CG) == 0)
@@ -297,15 +321,18 @@ __global__ __launch_bounds__(64 * CG * HH, 2) void collat256_kernel(Args a) {
         const uint32_t v = (tid & 15) ^ (((sr * kRps) >> 4) & 15);   // output image: slot ^ kb (see the stage-2 stores)
         const uint32_t k = sr * kRps + v / kCpr;
         const uint32_t chunk = v % kCpr;
-        u4 vr = *reinterpret_cast<const u4*>(img + 16 * (kT * i + tid));
-        u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 16 * (kT * i + tid));
-        if (k & 128) {                                                // kb >= 8: the two 8-byte halves were stored flipped
-          vr = u4{vr.z, vr.w, vr.x, vr.y};
-          vi = u4{vi.z, vi.w, vi.x, vi.y};
+        // (PP > 1: rows k = ka + 16 kb with ka in this workgroup's 16 / PP tiles; the other rows of the image were never written)
+        if (PP == 1 || ((k & 15) * PP) >> 4 == static_cast<uint32_t>(part)) {
+          u4 vr = *reinterpret_cast<const u4*>(img + 16 * (kT * i + tid));
+          u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 16 * (kT * i + tid));
+          if (k & 128) {                                                // kb >= 8: the two 8-byte halves were stored flipped
+            vr = u4{vr.z, vr.w, vr.x, vr.y};
+            vi = u4{vi.z, vi.w, vi.x, vi.y};
+          }
+          const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
+          *reinterpret_cast<u4*>(o_re + o) = vr;
+          *reinterpret_cast<u4*>(o_im + o) = vi;
         }
-        const uint64_t o = obase + (static_cast<uint64_t>(k) << a.ns_f_shift) + 8 * chunk;
-        *reinterpret_cast<u4*>(o_re + o) = vr;
-        *reinterpret_cast<u4*>(o_im + o) = vi;
       }
     }
     TFFT_WG_STAMP(a, 5);

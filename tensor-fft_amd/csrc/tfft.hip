@@ -586,10 +586,12 @@ struct Planes {
   X(8, false, true, false) X(8, false, true, true) X(8, true, true, false) X(4, false, false, false)         \
   X(4, false, false, true) X(4, true, false, false)
 
-// collat256_kernel<MODE, TW, CG, HH>: radix-256 pass for work that does not fill the chip (collat.hpp): 16 CG columns per workgroup,
-// a column group's stage 2 split over HH waves
-#define TFFT_COL_LAT_S(X, CG, HH) X(0, 0, CG, HH) X(0, 1, CG, HH) X(1, 0, CG, HH) X(1, 1, CG, HH)
-#define TFFT_COL_LAT(X) TFFT_COL_LAT_S(X, 4, 2) TFFT_COL_LAT_S(X, 2, 2) TFFT_COL_LAT_S(X, 1, 4)
+// collat256_kernel<MODE, TW, CG, HH, PP>: radix-256 pass for work that does not fill the chip (collat.hpp): 16 CG columns per
+// workgroup, a column group's stage 2 split over HH waves and PP workgroups
+#define TFFT_COL_LAT_S(X, CG, HH, PP) X(0, 0, CG, HH, PP) X(0, 1, CG, HH, PP) X(1, 0, CG, HH, PP) X(1, 1, CG, HH, PP)
+#define TFFT_COL_LAT(X)                                                                                      \
+  TFFT_COL_LAT_S(X, 4, 2, 1) TFFT_COL_LAT_S(X, 2, 2, 1) TFFT_COL_LAT_S(X, 1, 4, 1) TFFT_COL_LAT_S(X, 2, 2, 2) \
+  TFFT_COL_LAT_S(X, 2, 2, 4) TFFT_COL_LAT_S(X, 1, 4, 2)
 
 enum : uint32_t { kFamWave = 1, kFamWg256 = 2, kFam512 = 3, kFam512R = 4, kFam1024 = 5, kFamLat = 6 };
 using ColKernel = void (*)(colfft::Args);
@@ -629,9 +631,9 @@ const ColRow kColTable[] = {
    "colfft::colfft512r_wg_kernel<" #W ", " #SC ", " #PF ", " #PLAIN ">"},
     TFFT_COL_512R(X)
 #undef X
-#define X(MODE, TW, CG, HH)                                                                                          \
-  {col_key(kFamLat, MODE, TW, CG, HH), colfft::collat256_kernel<MODE, TW, CG, HH>, colfft::LatGeom<CG, HH>::kThreads,        \
-   colfft::LatGeom<CG, HH>::kLds, "colfft::collat256_kernel<" #MODE ", " #TW ", " #CG ", " #HH ">"},
+#define X(MODE, TW, CG, HH, PP)                                                                                      \
+  {col_key(kFamLat, MODE, TW, CG, HH, PP), colfft::collat256_kernel<MODE, TW, CG, HH, PP>, colfft::LatGeom<CG, HH, PP>::kThreads, \
+   colfft::LatGeom<CG, HH, PP>::kLds, "colfft::collat256_kernel<" #MODE ", " #TW ", " #CG ", " #HH ", " #PP ">"},
     TFFT_COL_LAT(X)
 #undef X
 };
@@ -845,14 +847,24 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     // 20.0 / 18.2 / 21.7.
     const int cgs = blocks64 <= 16 ? 1 : 2;
     const int hh = cgs == 1 ? 4 : 2;
-    int cgs_used = cgs, hh_used = hh;
+    // ... and beyond the workgroup: PP workgroups per block, each with the whole block in its LDS and 1 / PP of the stage-2 tiles
+    // and of the rows to store, while the pass has fewer workgroups than the chip has CUs (one wave per SIMD is the point) and
+    // every wave keeps two tiles. The partners READ the same block and WRITE disjoint bytes of dst: never for a pass in place.
+    const uint32_t wgs = static_cast<uint32_t>(blocks64 * 4 / cgs);
+    int pp = 1;
+    if (a.in_re != a.out_re && a.in_im != a.out_im)
+      while (pp < 4 && wgs * pp * 2 <= static_cast<uint32_t>(p->num_cus) && 16 / (hh * pp * 2) >= 2) pp *= 2;
+    int cgs_used = cgs, hh_used = hh, pp_used = pp;
 #ifdef TFFT_DEBUG_KERNELS
-    if (const uint32_t shape = env_iters("TFFT_LAT_SHAPE", 0)) {      // experiment knob: 42, 22, 14
-      cgs_used = static_cast<int>(shape / 10);
-      hh_used = static_cast<int>(shape % 10);
+    if (const uint32_t shape = env_iters("TFFT_LAT_SHAPE", 0)) {      // experiment knob, digits CG HH [PP]: 42, 22, 14; 222, 224, 142
+      const uint32_t two = shape >= 100 ? shape / 10 : shape;
+      cgs_used = static_cast<int>(two / 10);
+      hh_used = static_cast<int>(two % 10);
+      pp_used = shape >= 100 ? static_cast<int>(shape % 10) : 1;
     }
 #endif
-    return launch_col_row(p, col_key(kFamLat, mode, tw, cgs_used, hh_used), static_cast<uint32_t>(blocks64 * 4 / cgs_used), a, s);
+    return launch_col_row(p, col_key(kFamLat, mode, tw, cgs_used, hh_used, pp_used),
+                          static_cast<uint32_t>(blocks64 * 4 / cgs_used) * static_cast<uint32_t>(pp_used), a, s);
   }
   // variant bit 524288: 4-wave workgroups (two per CU) instead of one 8-wave workgroup
   static const uint32_t wg4_max_pitch_lanes = env_iters("TFFT_WG4_MAX_PITCH", 1024);          // experiment knobs
