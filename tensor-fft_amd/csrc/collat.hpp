@@ -37,8 +37,9 @@
 
 namespace colfft {
 
-// CG column groups of 16 columns per workgroup, HH waves per column group, PP workgroups per block (each takes 16 / PP of every
-// column group's stage-2 tiles and writes the rows that come out of them)
+// CG column groups of 16 columns per workgroup, HH waves per column group, PP = 1 or 2 workgroups per block (each takes 16 / PP of
+// every column group's stage-2 tiles and writes the rows that come out of them; four-way was built and measured: it loses what
+// two-way gains, profiles/r5_lat_shapes.txt)
 template <int CG, int HH, int PP = 1>
 struct LatGeom {
   static constexpr int kThreads = 64 * CG * HH;
@@ -51,7 +52,7 @@ struct LatGeom {
   static constexpr int kLds = kLdsTable + 2 * kPlane; // G (16 KiB) + one image
   static constexpr int kSplit = HH * PP;              // ways a column group's 16 stage-2 tiles are split
   static constexpr int kTiles = 16 / kSplit;          // stage-2 tiles per wave
-  static_assert(CG * HH <= 8 && kPieces >= 1 && (HH == 2 || HH == 4) && (PP == 1 || PP == 2 || PP == 4) && kTiles >= 2, "shape");
+  static_assert(CG * HH <= 8 && kPieces >= 1 && (HH == 2 || HH == 4) && (PP == 1 || PP == 2) && kTiles >= 2, "shape");
 };
 
 template <int MODE, int TW, int CG, int HH, int PP = 1>
@@ -283,8 +284,7 @@ __global__ __launch_bounds__(64 * CG * HH, 2) void collat256_kernel(Args a) {
     uint16_t* const o_im = a.out_im + bidx * a.out_stride;
     if (MODE == kColsOnLanes) {
       // the image is the block's output as it lies in memory: 16 CG columns x 512 contiguous bytes per plane, chunk c of column
-      // f (within its group of 16) at slot c ^ f. PP = 2: this workgroup made the chunks of parity `part`; PP = 4: the 8-byte half
-      // part & 1 of the chunks of parity part >> 1
+      // f (within its group of 16) at slot c ^ f. PP = 2: this workgroup made the chunks of parity `part`
 #pragma unroll
       for (int i = 0; i < kPieces; ++i) {
         const uint32_t col = (kT / 32) * i + (tid >> 5);          // column within the block
@@ -295,21 +295,11 @@ __global__ __launch_bounds__(64 * CG * HH, 2) void collat256_kernel(Args a) {
           const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 16 * (kT * i + tid));
           *reinterpret_cast<u4*>(o_re + o) = vr;
           *reinterpret_cast<u4*>(o_im + o) = vi;
-        } else if (PP == 2) {
-          if ((chunk & 1) == static_cast<uint32_t>(part)) {
-            const u4 vr = *reinterpret_cast<const u4*>(img + 16 * (kT * i + tid));
-            const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 16 * (kT * i + tid));
-            *reinterpret_cast<u4*>(o_re + o) = vr;
-            *reinterpret_cast<u4*>(o_im + o) = vi;
-          }
-        } else {
-          if ((chunk & 1) == static_cast<uint32_t>(part >> 1)) {
-            const uint32_t hb = 8 * (part & 1);
-            const u2 vr = *reinterpret_cast<const u2*>(img + 16 * (kT * i + tid) + hb);
-            const u2 vi = *reinterpret_cast<const u2*>(img + kPlane + 16 * (kT * i + tid) + hb);
-            *reinterpret_cast<u2*>(o_re + o + hb / 2) = vr;
-            *reinterpret_cast<u2*>(o_im + o + hb / 2) = vi;
-          }
+        } else if ((chunk & 1) == static_cast<uint32_t>(part)) {
+          const u4 vr = *reinterpret_cast<const u4*>(img + 16 * (kT * i + tid));
+          const u4 vi = *reinterpret_cast<const u4*>(img + kPlane + 16 * (kT * i + tid));
+          *reinterpret_cast<u4*>(o_re + o) = vr;
+          *reinterpret_cast<u4*>(o_im + o) = vi;
         }
       }
     } else {

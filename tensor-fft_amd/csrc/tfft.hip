@@ -587,11 +587,11 @@ struct Planes {
   X(4, false, false, true) X(4, true, false, false)
 
 // collat256_kernel<MODE, TW, CG, HH, PP>: radix-256 pass for work that does not fill the chip (collat.hpp): 16 CG columns per
-// workgroup, a column group's stage 2 split over HH waves and PP workgroups
+// workgroup, a column group's stage 2 split over HH waves and PP = 1 or 2 workgroups
 #define TFFT_COL_LAT_S(X, CG, HH, PP) X(0, 0, CG, HH, PP) X(0, 1, CG, HH, PP) X(1, 0, CG, HH, PP) X(1, 1, CG, HH, PP)
 #define TFFT_COL_LAT(X)                                                                                      \
   TFFT_COL_LAT_S(X, 4, 2, 1) TFFT_COL_LAT_S(X, 2, 2, 1) TFFT_COL_LAT_S(X, 1, 4, 1) TFFT_COL_LAT_S(X, 2, 2, 2) \
-  TFFT_COL_LAT_S(X, 2, 2, 4) TFFT_COL_LAT_S(X, 1, 4, 2)
+  TFFT_COL_LAT_S(X, 1, 4, 2)
 
 enum : uint32_t { kFamWave = 1, kFamWg256 = 2, kFam512 = 3, kFam512R = 4, kFam1024 = 5, kFamLat = 6 };
 using ColKernel = void (*)(colfft::Args);
@@ -847,16 +847,17 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     // 20.0 / 18.2 / 21.7.
     const int cgs = blocks64 <= 16 ? 1 : 2;
     const int hh = cgs == 1 ? 4 : 2;
-    // ... and beyond the workgroup: PP workgroups per block, each with the whole block in its LDS and 1 / PP of the stage-2 tiles
-    // and of the rows to store, while the pass has fewer workgroups than the chip has CUs (one wave per SIMD is the point) and
-    // every wave keeps two tiles. The partners READ the same block and WRITE disjoint bytes of dst: never for a pass in place.
+    // ... and beyond the workgroup: PP = 2 workgroups per block, each with the whole block in its LDS and half of the stage-2 tiles
+    // and of the rows to store, while that still leaves one workgroup per CU (one wave per SIMD is the point) and every wave keeps
+    // two tiles. One box, PP = 1 / 2 / 4 (profiles/r5_lat_shapes.txt, second part): 2^16 8.54 / 8.24 us, 2^17 11.50 / 11.18, 2^18
+    // 12.45 / 12.25, 2^19 14.39 / 13.80 / 14.17, 2^20 18.12 / 17.77 / 20.23, 2^21 (256 workgroups already) 26.0 / 27.5: 2-4 %, and
+    // four-way loses what two-way gains (every partner repeats the loads and stage 1). The partners READ the same block and WRITE
+    // disjoint bytes of dst: never for a pass in place.
     const uint32_t wgs = static_cast<uint32_t>(blocks64 * 4 / cgs);
-    int pp = 1;
-    if (a.in_re != a.out_re && a.in_im != a.out_im)
-      while (pp < 4 && wgs * pp * 2 <= static_cast<uint32_t>(p->num_cus) && 16 / (hh * pp * 2) >= 2) pp *= 2;
+    const int pp = (a.in_re != a.out_re && a.in_im != a.out_im && wgs * 2 <= static_cast<uint32_t>(p->num_cus) && 16 / (hh * 2) >= 2) ? 2 : 1;
     int cgs_used = cgs, hh_used = hh, pp_used = pp;
 #ifdef TFFT_DEBUG_KERNELS
-    if (const uint32_t shape = env_iters("TFFT_LAT_SHAPE", 0)) {      // experiment knob, digits CG HH [PP]: 42, 22, 14; 222, 224, 142
+    if (const uint32_t shape = env_iters("TFFT_LAT_SHAPE", 0)) {      // experiment knob, digits CG HH [PP]: 42, 22, 14; 222, 142
       const uint32_t two = shape >= 100 ? shape / 10 : shape;
       cgs_used = static_cast<int>(two / 10);
       hh_used = static_cast<int>(two % 10);

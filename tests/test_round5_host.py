@@ -99,7 +99,7 @@ def test_kernel_list_is_the_dispatch_table():
     for fam in ("colfft256_kernel<", "colfft256_wg_kernel<", "colfft512_wg_kernel<", "colfft512r_wg_kernel<", "colfft1024_wg_kernel<",
                 "collat256_kernel<"):
         assert any(fam in k for k in names), fam
-    assert "colfft::collat256_kernel<1, 1, 2, 2>" in names and "colfft::colfft512_wg_kernel<1, 2, false, true>" in names
+    assert "colfft::collat256_kernel<1, 1, 2, 2, 1>" in names and "colfft::collat256_kernel<0, 1, 1, 4, 2>" in names and "colfft::colfft512_wg_kernel<1, 2, false, true>" in names
 
 
 def test_reference_style_mains_exist_and_build():

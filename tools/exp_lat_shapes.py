@@ -1,5 +1,5 @@
 """Workgroup shapes of the latency column kernel (collat.hpp: columns per workgroup x waves per column group), in ONE process on
-the measurement build (TFFT_LAT_SHAPE = digits CG HH [PP]: 42 / 22 / 14 / 222 / 224 / 142, read at every launch; 0 = the throughput kernels via variant bit
+the measurement build (TFFT_LAT_SHAPE = digits CG HH [PP]: 42 / 22 / 14 / 222 / 142, read at every launch; 0 = the throughput kernels via variant bit
 1073741824): error against numpy's fp64 FFT and device time per transform (16 executions per HIP graph).
     python tools/exp_lat_shapes.py [lg[:batch] ...]"""
 import os, sys
@@ -23,7 +23,7 @@ for c in cases:
     x = torch.from_numpy(h).cuda().reshape(-1)
     y = torch.empty_like(x)
     line = f"N=2^{lg} x {b}:"
-    for shape in (0, 42, 22, 14, 222, 224, 142):
+    for shape in (0, 42, 22, 14, 222, 142):
         os.environ["TFFT_LAT_SHAPE"] = str(shape) if shape else "0"
         var = SPLIT_256 | (16777216 if lg < 16 else 0) | (NO_LAT if shape == 0 else 0)
         plan = tf.TfftPlan(n, b, 0, preserve_input=True, variant=var)
