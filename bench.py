@@ -427,6 +427,9 @@ def self_launch(n_ranks, script, script_args, nproc_visible=None):
     return rc
 
 
+_DIST_PROGRESS = {}       # the distributed entry's finished part, for the watchdog in main()
+
+
 def dist_2pow26(torch, tf, dist, rank, world, local_rank, reps=20, self_via_comm=False):
     """BASELINE configs[4b]: ONE transform of N = 2^26 spread over the `world` GPUs, four-step with a single RCCL exchange
     (tfft_dist_exec: column pass -> ncclSend / ncclRecv group -> row transforms, all on one stream). Every rank calls this;
@@ -568,7 +571,9 @@ def _dist_2pow26_body(torch, tf, dist, rank, world, f, n, why, want_native, self
     # the S = 1 figure above (whose three phases are separable because they run one after the other); every S must give S = 1's bits
     if f.transport == "rccl" and want_native:
         over = {}
+        _DIST_PROGRESS["report"] = dict(report)      # (what the watchdog prints if a rank gets stuck in the part below)
         for slabs in (2, 4):
+            _DIST_PROGRESS["stage"] = f"overlapped exchange, {slabs} slabs"
             err_s, ms_s, same = None, 0.0, False
             f2 = None
             try:
@@ -841,8 +846,14 @@ def main():
 
         def give_up():
             if rank == 0:
-                line.setdefault("other_configs", {})["configs[4b]_n2^26_distributed"] = {
-                    "error": f"timed out after {args.dist_timeout} s (a rank is stuck inside the entry; the headline above is unaffected)"}
+                why = f"timed out after {args.dist_timeout} s (a rank is stuck inside the entry; the headline above is unaffected)"
+                if "report" in _DIST_PROGRESS:      # the S = 1 transform and its phases were measured and checked: keep them
+                    rep = dict(_DIST_PROGRESS["report"])
+                    rep["overlapped_exchange"] = {"error": why + f"; stage: {_DIST_PROGRESS.get('stage')}"}
+                    rep["error"] = "overlapped exchange: " + why
+                else:
+                    rep = {"error": why}
+                line.setdefault("other_configs", {})["configs[4b]_n2^26_distributed"] = rep
                 print(json.dumps(line), flush=True)
             print(f"bench.py: rank {rank}: configs[4b] entry timed out after {args.dist_timeout} s", file=sys.stderr, flush=True)
             os._exit(3)
