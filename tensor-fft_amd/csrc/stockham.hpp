@@ -317,6 +317,85 @@ __global__ __launch_bounds__(kBlock) void pass_pair_kernel(PassArgs a) {
   }
 }
 
+// Final radix-128 pass of ONE or a few transforms (2^15 = 256 x 128 behind the latency column kernel, collat.hpp), workgroup-
+// cooperative: a radix-64 / radix-128 butterfly per THREAD (pass_kernel<64>) leaves a single 2^14 / 2^15 with one or two workgroups
+// of 256 threads that each grind through a thousand fp32 instructions and 256 two-byte memory instructions (2^14 as 256 x 64:
+// 13.5 us, profiles/r5_lat_shapes.txt). Here a workgroup takes 8 columns of the [128][m] matrix (16-byte row segments, ONE
+// vector load and ONE vector store per thread), and its 256 threads run the 128-point transforms of those columns as three
+// autosort steps 4 x 4 x 8 through LDS in fp32 (one rounding to binary16, at the end); the input twiddles were applied by the
+// column pass in front (skip_tw), and because this is the plan's last pass (Ns = m) output row k of column j is element
+// k m + j: the input's own layout. m % 8 == 0.
+constexpr int kCoopCols = 8;
+__global__ __launch_bounds__(kBlock) void tail128_coop_kernel(PassArgs a) {
+  __shared__ float s_re[2][128 * kCoopCols];
+  __shared__ float s_im[2][128 * kCoopCols];
+  __shared__ __attribute__((aligned(16))) _Float16 s_out[2][128 * kCoopCols];
+  const uint32_t t = threadIdx.x, c = t & 7, q = t >> 3;
+  const uint64_t tiles = a.m_f / kCoopCols;
+  const uint64_t fft = blockIdx.x / tiles;
+  const uint64_t j0 = (blockIdx.x - fft * tiles) * kCoopCols;
+  typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
+  {
+    // thread t < 128: row t of the RE plane, t >= 128: row t - 128 of the IM plane
+    const uint32_t row = t & 127;
+    const _Float16* src = (t < 128 ? a.in_re : a.in_im) + fft * a.in_stride + row * a.m_f + j0;
+    const hv8 v = *reinterpret_cast<const hv8*>(src);
+    float* dst = (t < 128 ? s_re[0] : s_im[0]) + row * kCoopCols;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = static_cast<float>(v[e]);
+  }
+  __syncthreads();
+  auto at = [&](int buf, uint32_t row) { return cf{s_re[buf][row * kCoopCols + c], s_im[buf][row * kCoopCols + c]}; };
+  auto put = [&](int buf, uint32_t row, cf v) {
+    s_re[buf][row * kCoopCols + c] = v.re;
+    s_im[buf][row * kCoopCols + c] = v.im;
+  };
+  auto w = [](uint32_t e, float inv) {       // exp(-2 pi i e inv): v_cos / v_sin take revolutions (|error| ~ 1e-6)
+    const float r = static_cast<float>(e) * inv;
+    return cf{__builtin_amdgcn_cosf(r), -__builtin_amdgcn_sinf(r)};
+  };
+  {  // step 1: radix 4, Ns = 1: j = q, y[4 j + i]
+    cf v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = at(0, q + 32 * i);
+    dft<4>(v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(1, 4 * q + i, v[i]);
+  }
+  __syncthreads();
+  {  // step 2: radix 4, Ns = 4: j = q, k = j & 3, twiddle w_16^(i k), y[(j - k) 4 + k + 4 i]
+    const uint32_t k = q & 3;
+    cf v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = at(1, q + 32 * i);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) v[i] = cmul(v[i], w(i * k, 1.0f / 16));
+    dft<4>(v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(0, (q - k) * 4 + k + 4 * i, v[i]);
+  }
+  __syncthreads();
+  if (q < 16) {  // step 3: radix 8, Ns = 16: j = k = q, twiddle w_128^(i k), output row k + 16 i
+    cf v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = at(0, q + 16 * i);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], w(i * q, 1.0f / 128));
+    dft<8>(v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s_out[0][(q + 16 * i) * kCoopCols + c] = static_cast<_Float16>(v[i].re * a.scale);
+      s_out[1][(q + 16 * i) * kCoopCols + c] = static_cast<_Float16>(v[i].im * a.scale);
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t row = t & 127;
+    _Float16* dst = (t < 128 ? a.out_re : a.out_im) + fft * a.out_stride + row * a.m_f + j0;
+    *reinterpret_cast<hv8*>(dst) = *reinterpret_cast<const hv8*>(s_out[t < 128 ? 0 : 1] + row * kCoopCols);
+  }
+}
+
 // plain planar copy (in-place requests whose pass chain cannot start from `in`)
 __global__ __launch_bounds__(kBlock) void copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                        uint64_t n32) {

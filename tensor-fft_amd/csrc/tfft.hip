@@ -307,7 +307,9 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
     const bool fuse_tail = !(variant & 2097152);
     if (fuse_tail && n256 >= 1 && radices.size() >= static_cast<size_t>(n256) + 2) {
       const size_t last = radices.size() - 1;
-      if (radices[last - 1] == 16 && (radices[last] == 2 || radices[last] == 4) && last - 1 == static_cast<size_t>(n256)) {
+      // (... and 2^15 = 256 x 16 x 8 into 256 x 128 with the workgroup-cooperative radix-128 pass, stockham::tail128_coop_kernel)
+      const bool coop128 = lg == 15 && inner == 1 && n256 == 1 && radices[0] == 256 && radices[last] == 8;
+      if (radices[last - 1] == 16 && (radices[last] == 2 || radices[last] == 4 || coop128) && last - 1 == static_cast<size_t>(n256)) {
         radices[last - 1] = 16 * radices[last];
         radices.pop_back();
       }
@@ -933,6 +935,16 @@ void launch_stockham_pass(const tfft_plan* p, const Pass& ps, Planes src, Planes
       default: launch_pass_pair<8>(a, p->batch, s); return;
     }
   }
+  if (R == 128) {      // (plan_passes emits it only as the last pass behind a column pass that applied its twiddles)
+    if (!a.skip_tw || a.ns != a.m_f || a.m_f % stockham::kCoopCols) {
+      (void)fail(TFFT_ERR_ARG, "internal error: radix-128 pass outside its geometry");
+      return;
+    }
+    if (!g_prepare)
+      hipLaunchKernelGGL(stockham::tail128_coop_kernel, dim3(static_cast<uint32_t>(a.m_f / stockham::kCoopCols * p->batch)),
+                         dim3(stockham::kBlock), 0, s, a);
+    return;
+  }
   switch (R) {
     case 2: launch_pass<2>(a, p->batch, s); break;
     case 4: launch_pass<4>(a, p->batch, s); break;
@@ -1294,9 +1306,13 @@ inline bool footprint_policy(uint64_t samples, uint64_t lo_mib) {
 inline int small_work_variant(uint64_t n, uint64_t inner, uint64_t batch) {
   if (inner != 1 || !is_pow2(n) || batch == 0 || batch > (1ull << 30)) return 0;
   const int lg = ilog2(n);
-  if (lg < 17 || lg > 21) return 0;
   const uint64_t work = n * batch;
   constexpr int kSplit256 = 8388608 | 33554432;          // no radix-512 / radix-1024 passes: 256 x 256 x R
+  // 2^15 up to 8 transforms: 256 x 128 on the latency column kernel + the cooperative radix-128 pass instead of the single-pass
+  // kernel, whose eight 4096-point sub-transforms share ONE CU (profiles/r5_small_scan.txt, last part: x 1: 12.0 -> 7.9 us, x 4:
+  // 12.2 -> 8.8, x 8: 12.3 -> 10.3, x 16: 12.3 against 14.6)
+  if (lg == 15) return work <= (1ull << 18) ? (kSplit256 | 16777216) : 0;
+  if (lg < 17 || lg > 21) return 0;
   if (work <= (lg <= 18 ? (1ull << 20) : (1ull << 22))) return kSplit256;
   if (lg == 18 && work <= (1ull << 22)) return 268435456;  // 512 x 512 with the single-round radix-512 kernel last (round 4: x 16: 32.5 -> 28.4 us)
   return 0;
@@ -1491,7 +1507,9 @@ int create_plan(uint64_t n, uint64_t batch, int device_id, const tfft_plan_opts*
 #endif
   const bool caller_facing = io.group_shift == 0 && !io.rows2d && io.in_seg_len == 0 && io.otw_n == 0;
   uint32_t launch_iters = opts->launch_iters;
-  const bool plannable = !tw4 && order == TFFT_ORDER_NATURAL && in_order == TFFT_ORDER_NATURAL && caller_facing;
+  // (a TFFT_ORDER_TRANSPOSED request for a length without an [N1][N2] layout IS the natural-order plan: same defaults)
+  const bool natural_out = order == TFFT_ORDER_NATURAL || !tfft_plan_transposed_n2(n);
+  const bool plannable = !tw4 && natural_out && in_order == TFFT_ORDER_NATURAL && caller_facing;
   if (pvariant == 0 && launch_iters == 0 && plannable && inner == 1) {
     int wv = 0;
     uint32_t wi = 0;

@@ -286,7 +286,7 @@ def test_n256r_single_pass_kernel(tf, torch, orc, n, batch):
     assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16)) and np.array_equal(o[:, 1].view(np.uint16), gi.view(np.uint16))
     d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
     o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
-    tf.TfftPlan(n, batch, 0, in_batch_stride=n, out_batch_stride=n).exec(d_re, d_im, o_re, o_im)
+    tf.TfftPlan(n, batch, 0, in_batch_stride=n, out_batch_stride=n, **kw).exec(d_re, d_im, o_re, o_im)
     torch.cuda.synchronize()
     assert np.array_equal(o_re.cpu().numpy().reshape(batch, n).view(np.uint16), gr.view(np.uint16))
     assert np.array_equal(o_im.cpu().numpy().reshape(batch, n).view(np.uint16), gi.view(np.uint16))
@@ -354,9 +354,12 @@ def test_n4096r_single_pass_kernel(tf, torch, orc, n, batch):
     rng = np.random.default_rng(n + batch)
     re = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
     im = rng.uniform(-1, 1, (batch, n)).astype(np.float16)
-    plan = tf.TfftPlan(n, batch, 0)
+    # (round 5: up to 8 transforms of 2^15 default to the two-launch plan 256 x 128, tfft_plan_default_variant; a caller that names
+    # any variant bit gets exactly that variant, and 1073741824 alone changes nothing about a single-pass plan)
+    kw = {"variant": 1073741824} if tf.plan_default_variant(n, 1, batch) else {}
+    plan = tf.TfftPlan(n, batch, 0, **kw)
     assert plan.kernel_name == "fft4096r_kernel" and plan.num_launches == 1 and plan.workspace_bytes == 0
-    gr, gi = _run(tf, torch, re, im)
+    gr, gi = _run(tf, torch, re, im, **kw)
     _check_against_oracle(orc, re, im, gr, gi, mode=orc.MODE_4096)
     dev = torch.from_numpy(np.ascontiguousarray(np.stack([re, im], axis=1))).cuda().reshape(-1)
     plan.exec(dev, dev[n:], dev, dev[n:])

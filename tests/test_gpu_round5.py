@@ -265,3 +265,41 @@ def test_mfma_flops_are_linear_in_the_batch_across_the_chunk_boundary(tf, lg, or
         per.append(f / batch)
         plan.close()
     assert max(per) - min(per) <= 1e-9 * max(per), per
+
+
+@pytest.mark.parametrize("batch", [1, 5, 8])
+def test_cooperative_radix128_pass(tf, orc, batch):
+    """2^15 = 256 x 128: the latency column kernel, then stockham::tail128_coop_kernel (8 columns per workgroup, 4 x 4 x 8 through
+    LDS in fp32): the default for up to 8 transforms. Against orc.dft64, against the single-pass kernel (two roundings apart at
+    most), in place, and with padded batch strides on both sides."""
+    import torch
+
+    n = 1 << 15
+    v = tf.plan_default_variant(n, 1, batch)
+    assert tf.plan_describe(n, 1, v) == "col:256+tw autosort:128-tw"
+    plan = tf.TfftPlan(n, batch, 0)
+    assert plan.num_launches == 2
+    y = _run(tf, torch, n, batch, 140 + batch)
+    assert _check(orc, y, n, batch, 140 + batch) <= REL_L2_TOL
+    y1 = _run(tf, torch, n, batch, 140 + batch, variant=NO_LAT)          # any explicit bit: exactly that variant = the single-pass kernel
+    d = (y.float() - y1.float()).double()
+    assert float(d.norm() / y1.double().norm()) <= 6e-4
+    x = torch.empty(batch * 2 * n, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x, x[n:], n, batch, seed=140 + batch)
+    work = x.clone()
+    plan.exec(work, work[n:], work, work[n:])
+    torch.cuda.synchronize()
+    assert bool((work.view(torch.int16) == y.view(torch.int16)).all())
+    plan.close()
+    pad_in, pad_out = 2 * n + 512, 2 * n + 1024
+    xp = torch.zeros(batch * pad_in, dtype=torch.float16, device="cuda")
+    yp = torch.full((batch * pad_out,), float("nan"), dtype=torch.float16, device="cuda")
+    for b in range(batch):
+        xp[b * pad_in:b * pad_in + 2 * n] = x[b * 2 * n:(b + 1) * 2 * n]
+    plan = tf.TfftPlan(n, batch, 0, in_batch_stride=pad_in, out_batch_stride=pad_out, preserve_input=True)
+    plan.exec(xp, xp[n:], yp, yp[n:])
+    torch.cuda.synchronize()
+    for b in range(batch):
+        assert bool((yp[b * pad_out:b * pad_out + 2 * n].view(torch.int16) == y[b * 2 * n:(b + 1) * 2 * n].view(torch.int16)).all())
+        assert bool(torch.isnan(yp[b * pad_out + 2 * n:(b + 1) * pad_out]).all())
+    plan.close()

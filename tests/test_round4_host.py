@@ -121,10 +121,13 @@ def test_small_work_gets_the_split_with_more_workgroups():
     assert D(1 << 21, 1, V(1 << 21, 1, 1)) == "col:256+tw col:256+tw autosort:32-tw"
     assert V(1 << 17, 1, 1) == S and V(1 << 17, 1, 8) == S and V(1 << 17, 1, 16) == 0 and V(1 << 17, 1, 64) == 0
     assert D(1 << 17, 1, V(1 << 17, 1, 1)) == "col:256+tw col:256+tw autosort:2-tw"
-    for lg in (8, 12, 16, 22, 24, 25, 26):
+    # 2^15 up to 8 transforms: 256 x 128 (latency column kernel + the workgroup-cooperative radix-128 pass) instead of the single-pass kernel
+    assert V(1 << 15, 1, 1) == (S | 16777216) and V(1 << 15, 1, 8) == (S | 16777216) and V(1 << 15, 1, 16) == 0 and V(1 << 15, 1, 8192) == 0
+    assert D(1 << 15, 1, V(1 << 15, 1, 1)) == "col:256+tw autosort:128-tw" and D(1 << 15, 1, 0) == "k4096r:8"
+    for lg in (8, 12, 13, 14, 16, 22, 24, 25, 26):
         assert V(1 << lg, 1, 1) == 0 and V(1 << lg, 1, 2) == 0
     assert V(1 << 20, 64, 1) == 0 and V(3 << 19, 1, 1) == 0 and V(1 << 20, 1, 0) == 0
-    for lg, b in ((17, 1), (18, 1), (18, 16), (19, 4), (20, 4), (21, 1)):                          # every value it returns is a variant the library accepts
+    for lg, b in ((15, 1), (17, 1), (18, 1), (18, 16), (19, 4), (20, 4), (21, 1)):                          # every value it returns is a variant the library accepts
         capi.variant_check(1 << lg, 1, V(1 << lg, 1, b))
 
 
