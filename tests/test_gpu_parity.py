@@ -286,7 +286,7 @@ def test_n256r_single_pass_kernel(tf, torch, orc, n, batch):
     assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16)) and np.array_equal(o[:, 1].view(np.uint16), gi.view(np.uint16))
     d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
     o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
-    tf.TfftPlan(n, batch, 0, in_batch_stride=n, out_batch_stride=n, **kw).exec(d_re, d_im, o_re, o_im)
+    tf.TfftPlan(n, batch, 0, in_batch_stride=n, out_batch_stride=n).exec(d_re, d_im, o_re, o_im)
     torch.cuda.synchronize()
     assert np.array_equal(o_re.cpu().numpy().reshape(batch, n).view(np.uint16), gr.view(np.uint16))
     assert np.array_equal(o_im.cpu().numpy().reshape(batch, n).view(np.uint16), gi.view(np.uint16))
@@ -368,7 +368,7 @@ def test_n4096r_single_pass_kernel(tf, torch, orc, n, batch):
     assert np.array_equal(o[:, 0].view(np.uint16), gr.view(np.uint16)) and np.array_equal(o[:, 1].view(np.uint16), gi.view(np.uint16))
     d_re, d_im = torch.from_numpy(re).cuda().reshape(-1), torch.from_numpy(im).cuda().reshape(-1)
     o_re, o_im = torch.empty_like(d_re), torch.empty_like(d_im)
-    tf.TfftPlan(n, batch, 0, in_batch_stride=n, out_batch_stride=n).exec(d_re, d_im, o_re, o_im)
+    tf.TfftPlan(n, batch, 0, in_batch_stride=n, out_batch_stride=n, **kw).exec(d_re, d_im, o_re, o_im)
     torch.cuda.synchronize()
     assert np.array_equal(o_re.cpu().numpy().reshape(batch, n).view(np.uint16), gr.view(np.uint16))
     assert np.array_equal(o_im.cpu().numpy().reshape(batch, n).view(np.uint16), gi.view(np.uint16))
@@ -389,7 +389,8 @@ def test_radix512_column_pass(tf, torch, orc, lg, batch):
     plan = tf.TfftPlan(n, batch, 0, variant=multi)
     no512 = multi | 8388608 | 33554432           # (without the radix-1024 pass either, which would stand in at 2^18)
     other = tf.TfftPlan(n, batch, 0, variant=no512)
-    assert plan.num_launches == other.num_launches - 1
+    # (2^15 without the radix-512 pass is 256 x 128 with the cooperative radix-128 pass since round 5: two launches as well)
+    assert plan.num_launches == other.num_launches - (0 if lg == 15 else 1)
     gr, gi = _run(tf, torch, re, im, variant=multi)
     exact = _c(*orc.dft64(re, im))
     got = _c(gr, gi)

@@ -283,7 +283,7 @@ def test_cooperative_radix128_pass(tf, orc, batch):
     assert _check(orc, y, n, batch, 140 + batch) <= REL_L2_TOL
     y1 = _run(tf, torch, n, batch, 140 + batch, variant=NO_LAT)          # any explicit bit: exactly that variant = the single-pass kernel
     d = (y.float() - y1.float()).double()
-    assert float(d.norm() / y1.double().norm()) <= 6e-4
+    assert float(d.norm() / y1.double().norm()) <= 8e-4          # (two results, each within 5e-4 of the exact one)
     x = torch.empty(batch * 2 * n, dtype=torch.float16, device="cuda")
     tf.synth_uniform(x, x[n:], n, batch, seed=140 + batch)
     work = x.clone()
