@@ -274,7 +274,12 @@ int tfft_plan_describe(uint64_t n, uint64_t inner, int variant, char* buf, size_
 
 /* Number of passes over the data one tfft_exec makes (= kernel launches, except that a narrow column pass with a
  * ragged batch takes two) and the bytes of device scratch it needs beyond in/out (0 for N <= 32768 with a contiguous axis). If nonzero, either hand memory in
- * with tfft_plan_set_workspace(), call tfft_plan_prepare() once, or let the first tfft_exec hipMalloc it. */
+ * with tfft_plan_set_workspace(), call tfft_plan_prepare() once, or let the first tfft_exec hipMalloc it.
+ * IN PLACE (out == in) a plan with an odd number >= 3 of passes needs a third buffer: a library-owned workspace grows to twice
+ * tfft_plan_workspace_bytes() at the first such call (a hipMalloc: not under stream capture), a caller's workspace of twice that
+ * size is used the same way, and with a smaller caller's workspace the chain starts from a copy of the input instead (one more
+ * launch, and the [RE | IM] block layout with batch stride 2 n is then required). The reference's plans say where the spectrum
+ * ends up (results_in_results_, src/base/Plan.h:141-145): for 2^18 and 2^21 that is the input half, i.e. in place. */
 int tfft_plan_num_launches(const tfft_plan* plan);
 size_t tfft_plan_workspace_bytes(const tfft_plan* plan);
 int tfft_plan_set_workspace(tfft_plan* plan, void* device_ptr, size_t bytes);

@@ -955,9 +955,11 @@ void launch_stockham_pass(const tfft_plan* p, const Pass& ps, Planes src, Planes
   }
 }
 
-int ensure_workspace(const tfft_plan* p) {
+// blocks = 2: a second block behind the first (in-place execution of a plan with an odd number of passes, launch_chain); only
+// asked for when the workspace is the library's own or the caller's is large enough (workspace_blocks_available)
+int ensure_workspace(const tfft_plan* p, size_t blocks = 1) {
   std::lock_guard<std::mutex> lock(p->ws_mutex);
-  const size_t need = tfft_plan_workspace_bytes(p);
+  const size_t need = tfft_plan_workspace_bytes(p) * blocks;
   if (need == 0 || (p->ws && p->ws_bytes >= need)) return TFFT_OK;
   if (p->ws && !p->ws_owned) return fail(TFFT_ERR_WORKSPACE, "workspace handed to tfft_plan_set_workspace is too small");
   if (p->ws) (void)hipFree(p->ws);
@@ -1032,12 +1034,29 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
   const bool use_in_as_scratch = !p->preserve_input && !in_place && odd;
   Planes SCR = IN;
   Planes SRC = IN;
+  // In place with an odd number (>= 3) of passes: the chain needs a third buffer, IN -> A -> B -> ... -> OUT (= IN). A second
+  // workspace block behind the first when the workspace is the library's own (or a caller's of twice tfft_plan_workspace_bytes);
+  // otherwise, and for a single pass, the chain starts from a copy of the input (one more launch: the reference's own
+  // single-transform benchmark runs 2^18 and 2^21 in place, results_in_results_ = false, and paid 3 / 11 us for that copy).
+  Planes SCR_B{};
+  bool two_blocks = false;
+  if (in_place && odd && np >= 3 && !g_prepare) {
+    bool can;
+    {
+      std::lock_guard<std::mutex> lock(p->ws_mutex);
+      can = !p->ws || p->ws_owned || p->ws_bytes >= 2 * tfft_plan_workspace_bytes(p);
+    }
+    two_blocks = can;
+  }
   if (!use_in_as_scratch && (np > 1 || in_place) && !g_prepare) {
-    const int rc = ensure_workspace(p);
+    const int rc = ensure_workspace(p, two_blocks ? 2 : 1);
     if (rc) return rc;
     _Float16* w = static_cast<_Float16*>(p->ws);
     SCR = Planes{w, w + nf, 2 * nf};
-    if (in_place && odd) {
+    if (two_blocks) {
+      _Float16* w2 = w + p->batch * 2 * nf;
+      SCR_B = Planes{w2, w2 + nf, 2 * nf};
+    } else if (in_place && odd) {
       // chain IN -> OUT would read and write the same block: start from a copy.
       if (p->in_stride != 2 * nf || static_cast<const _Float16*>(in_im) != static_cast<const _Float16*>(in_re) + nf)
         return fail(TFFT_ERR_ARG, "in-place execution of this length needs the [RE|IM] block layout (batch stride 2N)");
@@ -1050,7 +1069,7 @@ int launch_chain(const tfft_plan* p, const void* in_re, const void* in_im, void*
   Planes cur = SRC;
   for (int i = 0; i < np; ++i) {
     const bool to_out = ((np - 1 - i) % 2) == 0;
-    const Planes dst = to_out ? OUT : SCR;
+    const Planes dst = two_blocks ? (i + 1 == np ? OUT : ((i % 2) ? SCR_B : SCR)) : (to_out ? OUT : SCR);
     const Pass& ps = p->passes[i];
     if (ps.kind == PassKind::Col256) {
       const int rc = launch_col(p, ps, cur, dst, s);

@@ -303,3 +303,28 @@ def test_cooperative_radix128_pass(tf, orc, batch):
         assert bool((yp[b * pad_out:b * pad_out + 2 * n].view(torch.int16) == y[b * 2 * n:(b + 1) * 2 * n].view(torch.int16)).all())
         assert bool(torch.isnan(yp[b * pad_out + 2 * n:(b + 1) * pad_out]).all())
     plan.close()
+
+
+@pytest.mark.parametrize("lg,batch", [(18, 1), (18, 3), (21, 1), (17, 2)])
+def test_in_place_with_two_workspace_blocks(tf, orc, lg, batch):
+    """In place, odd number of passes (three): with a workspace of twice tfft_plan_workspace_bytes the chain runs IN -> A -> B -> IN
+    without the leading copy; with the plain workspace it starts from a copy. Both give the out-of-place bits."""
+    import torch
+
+    n = 1 << lg
+    x = torch.empty(batch * 2 * n, dtype=torch.float16, device="cuda")
+    tf.synth_uniform(x, x[n:], n, batch, seed=160 + lg)
+    plan = tf.TfftPlan(n, batch, 0, preserve_input=True)      # (otherwise the out-of-place run below may use x as its scratch)
+    assert plan.num_launches == 3
+    ref = torch.empty_like(x)
+    plan.exec(x, x[n:], ref, ref[n:])
+    torch.cuda.synchronize()
+    assert _check(orc, ref, n, batch, 160 + lg, ids=(0, batch - 1)) <= REL_L2_TOL
+    for blocks in (1, 2):
+        ws = torch.empty(blocks * plan.workspace_bytes // 2, dtype=torch.float16, device="cuda")
+        plan.set_workspace(ws)
+        work = x.clone()
+        plan.exec(work, work[n:], work, work[n:])
+        torch.cuda.synchronize()
+        assert bool((work.view(torch.int16) == ref.view(torch.int16)).all()), blocks
+    plan.close()
