@@ -38,7 +38,8 @@ struct RunResults {
 // the knobs that exist for this length (BenchUtil.h:77-104 GetSearchSpace: what the device allows)
 std::vector<RunConfig> GetRunConfigs(long long fft_length) {
   static const int kVariants[] = {0, 32, 524288, 8388608, 33554432, 8388608 | 33554432, 134217728, 16777216, 2097152, 268435456,
-                                  1048576, 262144, 536870912, 1073741824, 1073741824 | 8388608 | 33554432};
+                                  1048576, 262144, 536870912, 1073741824, 1073741824 | 8388608 | 33554432,
+                                  8388608 | 33554432 | 16777216};      // (2^15 as 256 x 128 with the cooperative radix-128 pass)
   static const int kIters[] = {0, 1, 2, 4, 8, TFFT_LAUNCH_PERSISTENT};
   std::vector<RunConfig> configs;
   char base[256], desc[256];

@@ -38,7 +38,7 @@ def candidates(n):
     if n < 8192:
         return [0, 32]
     if n <= 32768:
-        return [0, 16777216, 16777216 | 8388608, 32]
+        return [0, 16777216, 16777216 | 8388608, 16777216 | 8388608 | 33554432, 32]     # (the last but one: 2^15 as 256 x 128, cooperative radix-128 pass)
     return [0, 32, 524288, 2097152, 1048576, 8388608, 33554432, 8388608 | 33554432, 134217728, 268435456, 262144, 536870912]
 
 
