@@ -131,7 +131,10 @@ typedef struct tfft_plan_opts {
                            radix-16 + radix-2/4 tail into one radix-32/64 pass; 8388608 = no radix-512 column
                            passes; 33554432 = no radix-1024 column passes; 134217728 = among the splits with the
                            fewest passes, the one with the most radix-1024 (then radix-512) passes instead of the
-                           measured default; 16777216 = N = 8192..32768 as a column plan instead of the single-pass kernel (2^15: 512 x 64; together with 8388608 | 33554432: 256 x 128 with the cooperative radix-128 final pass); 4194304 = one butterfly per thread in the radix-2/4/8 tail pass.
+                           measured default; 16777216 = N = 8192..32768 as a column plan instead of the single-pass kernel (2^15: 512 x 64; together with 8388608 | 33554432: 256 x 128 with the cooperative radix-128 final pass); 4194304 = one butterfly per thread in the radix-2/4/8 tail pass
+                           (and in the radix-64 pass of a small batch of 2^14), and the packed launch shape of the single-pass
+                           kernels (eight working waves per workgroup) for a batch that does not fill the chip, which by default
+                           spreads over the CUs with at most one working wave per SIMD (same results bit for bit).
                            268435456 = a final radix-512 pass by the other of its two kernels: the two-round kernel
                            (colfft512r.hpp: 128-column tiles, or 64-column tiles and two 4-wave workgroups per CU with bit
                            524288) where the 8-wave single-round kernel is the default, and vice versa (default: two-round
@@ -234,7 +237,8 @@ int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch);
  * as 256 x 256 x 16 with the latency column kernel it takes 18 us): 2^17 ... 2^21 up to 2^20 (2^17, 2^18) / 2^22 (2^19 ... 2^21)
  * samples per launch; 2^18 up to 2^22 samples: the other radix-512 kernel; 2^15 up to 8 transforms: 256 x 128 (8388608 |
  * 33554432 | 16777216: the latency column kernel + a workgroup-cooperative radix-128 pass, 7.3 us for one transform where the
- * single-pass kernel, one CU, takes 11.3). Measured limits: profiles/r5_small_scan.txt. The
+ * single-pass kernel, one CU, takes 11.3); 2^14 up to 4 transforms: 256 x 64 the same way (8.4 -> 7.2 us). Measured limits:
+ * profiles/r5_small_scan.txt. The
  * within-noise rules of round 4 (two 2^24, a single 2^25) are wisdom lines now (profiles/r5_TunerResults.dat), not code.
  * Independent of the variant, radix-256 column passes of at most 64 blocks (128 from a row pitch of 512 columns on) run as the
  * latency kernel (collat.hpp) unless the variant holds 1073741824.

@@ -33,7 +33,7 @@ constexpr int kFftsPerWave = 16;
 template <bool OTW = false>
 __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                              uint16_t* out_re, uint16_t* out_im, Addr in_map,
-                                                             Addr out_map, uint32_t batch,
+                                                             Addr out_map, uint32_t batch, uint32_t live,
                                                              const uint8_t* __restrict__ tables, OutTw otw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft256_kernel(const uint16_t* in_
 #endif
 
   const uint32_t groups = (batch + kFftsPerWave - 1) / kFftsPerWave;
-  for (uint32_t grp = blockIdx.x * kWavesPerBlock + wave; grp < groups; grp += gridDim.x * kWavesPerBlock) {
+  // (live: waves of a workgroup that take groups, 8 or fewer for a small batch: k4096.hpp, tfft.hip live_waves())
+  for (uint32_t grp = static_cast<uint32_t>(wave) < live ? blockIdx.x * live + wave : groups; grp < groups; grp += gridDim.x * live) {
     const uint32_t b0 = grp * kFftsPerWave;
     const uint32_t nb = (batch - b0 < kFftsPerWave) ? (batch - b0) : kFftsPerWave;   // ragged last group
 #pragma unroll

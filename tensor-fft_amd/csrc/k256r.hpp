@@ -111,7 +111,7 @@ inline void build_tables(int R, std::vector<uint8_t>& blob, double fa = 1.0 / 16
 template <int R, bool STG = true, bool OTW = false>
 __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                               uint16_t* out_re, uint16_t* out_im, Addr in_map,
-                                                              Addr out_map, uint32_t batch,
+                                                              Addr out_map, uint32_t batch, uint32_t live,
                                                               const uint8_t* __restrict__ tables, OutTw otw) {
   constexpr int kPerWave = 16 / R;          // transforms per wave iteration
   constexpr int kPlane = 512 * R;           // bytes of one plane of one transform
@@ -159,7 +159,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft256r_kernel(const uint16_t* in
 #endif
 
   const uint32_t groups = (batch + kPerWave - 1) / kPerWave;
-  for (uint32_t grp = blockIdx.x * kWavesPerBlock + wave; grp < groups; grp += gridDim.x * kWavesPerBlock) {
+  // (live: waves of a workgroup that take groups, 8 or fewer for a small batch: k4096.hpp, tfft.hip live_waves())
+  for (uint32_t grp = static_cast<uint32_t>(wave) < live ? blockIdx.x * live + wave : groups; grp < groups; grp += gridDim.x * live) {
     const uint32_t b0 = grp * kPerWave;
     const uint32_t nb = (batch - b0 < kPerWave) ? (batch - b0) : kPerWave;   // ragged last group
 #pragma unroll

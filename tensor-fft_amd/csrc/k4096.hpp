@@ -348,7 +348,7 @@ __device__ __forceinline__ void st(uint16_t* p, u4 v) {
 template <int V, bool OTW = false>
 __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
     const uint16_t* in_re, const uint16_t* in_im, uint16_t* out_re, uint16_t* out_im, Addr in_map,
-    Addr out_map, uint32_t batch, const uint8_t* __restrict__ tables, OutTw otw) {
+    Addr out_map, uint32_t batch, uint32_t live, const uint8_t* __restrict__ tables, OutTw otw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -359,8 +359,11 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096_kernel(
   const uint32_t wl_off = __builtin_amdgcn_readfirstlane(
       static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)wl)));
 
-  const uint32_t stride_b = gridDim.x * kWavesPerBlock;
-  uint32_t b = blockIdx.x * kWavesPerBlock + wave;
+  // live = waves of a workgroup that take transforms: 8, or fewer for a batch that does not fill the chip (tfft.hip live_waves():
+  // one wave per SIMD, on as many CUs as there are; N = 4096 x 8 ... x 1024: 8.4-8.7 us with eight waves per CU, 5.7-6.3 with up to
+  // four). The other waves help to fill the tables and leave.
+  const uint32_t stride_b = gridDim.x * live;
+  uint32_t b = static_cast<uint32_t>(wave) < live ? blockIdx.x * live + wave : batch;
 
   // G and H into LDS, once per workgroup.
   for (int i = tid; i < kLdsTableBytes / 16; i += kThreads)

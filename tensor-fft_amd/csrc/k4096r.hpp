@@ -53,7 +53,7 @@ using namespace k4096;
 template <int R, bool ROWS = false, bool OTW = false>
 __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* in_re, const uint16_t* in_im,
                                                                uint16_t* out_re, uint16_t* out_im, Addr in_map,
-                                                               Addr out_map, uint32_t batch,
+                                                               Addr out_map, uint32_t batch, uint32_t gstep,
                                                                const uint8_t* __restrict__ tables, OutTw otw
 #ifdef TFFT_DEBUG_KERNELS
                                                                , unsigned long long* stamps   // tools/exp_rows_phases.py; null in normal use
@@ -115,7 +115,10 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   const uint32_t out_chunk = 4096u * s;     // this wave stores halves [4096 s, 4096 (s + 1)) of each output plane
 
   static_assert(!ROWS || R == 8, "the 2D row form takes the 8 rows r0 + 512 i of an image");
-  const uint32_t groups_total = ROWS ? batch : (batch + kGroups - 1) / kGroups;
+  // gstep = transforms per workgroup iteration: kGroups, or 1 for a batch of at most one transform per CU (tfft.hip): then only
+  // group 0 of every workgroup has work, its R waves alone on the CU's SIMDs (2^13 x 4: 11.7 us with four transforms on one CU,
+  // 7.6 us spread over four, profiles/r5_small_scan.txt)
+  const uint32_t groups_total = ROWS ? batch : (batch + gstep - 1) / gstep;
   constexpr int kPs = 8 / R;                 // 16-byte chunks per lane, block and plane that this wave owns
 
   // Raw samples of one iteration, straight from HBM into registers, already in the shape of MFMA B operands: the
@@ -130,10 +133,10 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
   const int fg = lane >> 4, fn = lane & 15;
   u4 raw[4][4];
   auto issue_loads = [&](uint32_t it) {
-    const uint32_t b_raw = ROWS ? (it >> 9) : it * kGroups + grp;
+    const uint32_t b_raw = ROWS ? (it >> 9) : it * gstep + grp;
     // a group past the end of the batch loads nothing (round 5: it used to re-read the last transform, harmless in a full batch,
     // but for ONE transform of 2^13 that is 128 KiB through the CU's load path instead of 32 KiB)
-    if (!ROWS && __builtin_amdgcn_readfirstlane(static_cast<int>(b_raw >= batch))) return;
+    if (!ROWS && __builtin_amdgcn_readfirstlane(static_cast<int>(b_raw >= batch || static_cast<uint32_t>(grp) >= gstep))) return;
     const uint32_t b = b_raw;
     const uint32_t r0 = it & 511;
     const uint64_t base = in_map.off(b) + (ROWS ? static_cast<uint64_t>(r0) * 4096 : 0);
@@ -183,8 +186,8 @@ __global__ __launch_bounds__(kThreads, 2) void fft4096r_kernel(const uint16_t* i
     // (Through round 4 it re-did the last transform without storing. For ONE transform of 2^13 that is six of eight waves doing
     // useless work on the SIMDs the two live waves need: the phase clock showed them waiting 1.2 + 1.7 us at barriers B and C and
     // running the stages in 2.6 us instead of 1.3: profiles/r5_k4096r_phases.txt; 2^13 x 1: 10.1 us per transform.)
-    const uint32_t b_raw = ROWS ? (it >> 9) : it * kGroups + grp;      // ROWS: image index; r0 = it & 511
-    const bool live = ROWS || b_raw < batch;
+    const uint32_t b_raw = ROWS ? (it >> 9) : it * gstep + grp;      // ROWS: image index; r0 = it & 511
+    const bool live = ROWS || (b_raw < batch && static_cast<uint32_t>(grp) < gstep);
     const uint32_t b = live ? b_raw : batch - 1;
     const uint32_t r0 = it & 511;
 

@@ -317,30 +317,33 @@ __global__ __launch_bounds__(kBlock) void pass_pair_kernel(PassArgs a) {
   }
 }
 
-// Final radix-128 pass of ONE or a few transforms (2^15 = 256 x 128 behind the latency column kernel, collat.hpp), workgroup-
-// cooperative: a radix-64 / radix-128 butterfly per THREAD (pass_kernel<64>) leaves a single 2^14 / 2^15 with one or two workgroups
+// Final radix-64 / radix-128 pass of ONE or a few transforms (2^14 = 256 x 64, 2^15 = 256 x 128 behind the latency column kernel,
+// collat.hpp), workgroup-cooperative: a radix-64 butterfly per THREAD (pass_kernel<64>) leaves a single 2^14 with one workgroup
 // of 256 threads that each grind through a thousand fp32 instructions and 256 two-byte memory instructions (2^14 as 256 x 64:
-// 13.5 us, profiles/r5_lat_shapes.txt). Here a workgroup takes 8 columns of the [128][m] matrix (16-byte row segments, ONE
-// vector load and ONE vector store per thread), and its 256 threads run the 128-point transforms of those columns as three
-// autosort steps 4 x 4 x 8 through LDS in fp32 (one rounding to binary16, at the end); the input twiddles were applied by the
-// column pass in front (skip_tw), and because this is the plan's last pass (Ns = m) output row k of column j is element
-// k m + j: the input's own layout. m % 8 == 0.
+// 13.5 us, profiles/r5_lat_shapes.txt). Here a workgroup of 2 R threads takes 8 columns of the [R][m] matrix (16-byte row
+// segments, ONE vector load and ONE vector store per thread) and runs the R-point transforms of those columns as three autosort
+// steps 4 x 4 x 4 (R = 64) or 4 x 4 x 8 (R = 128) through LDS in fp32 (one rounding to binary16, at the end); the input twiddles
+// were applied by the column pass in front (skip_tw), and because this is the plan's last pass (Ns = m) output row k of column j
+// is element k m + j: the input's own layout. m % 8 == 0. (The same pass for R = 512 ... 2048 loses to the three-launch plans,
+// profiles/r5_coop_tail_radices.txt.)
 constexpr int kCoopCols = 8;
-__global__ __launch_bounds__(kBlock) void tail128_coop_kernel(PassArgs a) {
-  __shared__ float s_re[2][128 * kCoopCols];
-  __shared__ float s_im[2][128 * kCoopCols];
-  __shared__ __attribute__((aligned(16))) _Float16 s_out[2][128 * kCoopCols];
-  const uint32_t t = threadIdx.x, c = t & 7, q = t >> 3;
+template <int R>
+__global__ __launch_bounds__(2 * R) void tail_coop_kernel(PassArgs a) {
+  static_assert(R == 64 || R == 128, "4 x 4 x 4 or 4 x 4 x 8");
+  __shared__ float s_re[2][R * kCoopCols];
+  __shared__ float s_im[2][R * kCoopCols];
+  __shared__ __attribute__((aligned(16))) _Float16 s_out[2][R * kCoopCols];
+  const uint32_t t = threadIdx.x, c = t & 7, q = t >> 3;       // q < R / 4: one radix-4 butterfly per thread and step
   const uint64_t tiles = a.m_f / kCoopCols;
   const uint64_t fft = blockIdx.x / tiles;
   const uint64_t j0 = (blockIdx.x - fft * tiles) * kCoopCols;
   typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
   {
-    // thread t < 128: row t of the RE plane, t >= 128: row t - 128 of the IM plane
-    const uint32_t row = t & 127;
-    const _Float16* src = (t < 128 ? a.in_re : a.in_im) + fft * a.in_stride + row * a.m_f + j0;
+    // thread t < R: row t of the RE plane, t >= R: row t - R of the IM plane
+    const uint32_t row = t & (R - 1);
+    const _Float16* src = (t < R ? a.in_re : a.in_im) + fft * a.in_stride + row * a.m_f + j0;
     const hv8 v = *reinterpret_cast<const hv8*>(src);
-    float* dst = (t < 128 ? s_re[0] : s_im[0]) + row * kCoopCols;
+    float* dst = (t < R ? s_re[0] : s_im[0]) + row * kCoopCols;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dst[e] = static_cast<float>(v[e]);
   }
@@ -354,10 +357,14 @@ __global__ __launch_bounds__(kBlock) void tail128_coop_kernel(PassArgs a) {
     const float r = static_cast<float>(e) * inv;
     return cf{__builtin_amdgcn_cosf(r), -__builtin_amdgcn_sinf(r)};
   };
+  auto out = [&](uint32_t row, cf v) {
+    s_out[0][row * kCoopCols + c] = static_cast<_Float16>(v.re * a.scale);
+    s_out[1][row * kCoopCols + c] = static_cast<_Float16>(v.im * a.scale);
+  };
   {  // step 1: radix 4, Ns = 1: j = q, y[4 j + i]
     cf v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = at(0, q + 32 * i);
+    for (int i = 0; i < 4; ++i) v[i] = at(0, q + (R / 4) * i);
     dft<4>(v);
 #pragma unroll
     for (int i = 0; i < 4; ++i) put(1, 4 * q + i, v[i]);
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void tail128_coop_kernel(PassArgs a) {
     const uint32_t k = q & 3;
     cf v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = at(1, q + 32 * i);
+    for (int i = 0; i < 4; ++i) v[i] = at(1, q + (R / 4) * i);
 #pragma unroll
     for (int i = 1; i < 4; ++i) v[i] = cmul(v[i], w(i * k, 1.0f / 16));
     dft<4>(v);
@@ -375,7 +382,16 @@ __global__ __launch_bounds__(kBlock) void tail128_coop_kernel(PassArgs a) {
     for (int i = 0; i < 4; ++i) put(0, (q - k) * 4 + k + 4 * i, v[i]);
   }
   __syncthreads();
-  if (q < 16) {  // step 3: radix 8, Ns = 16: j = k = q, twiddle w_128^(i k), output row k + 16 i
+  if (R == 64) {  // step 3: radix 4, Ns = 16: j = k = q < 16, twiddle w_64^(i k), output row k + 16 i
+    cf v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = at(0, q + 16 * i);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) v[i] = cmul(v[i], w(i * q, 1.0f / 64));
+    dft<4>(v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out(q + 16 * i, v[i]);
+  } else if (q < 16) {  // step 3: radix 8, Ns = 16: j = k = q, twiddle w_128^(i k), output row k + 16 i
     cf v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = at(0, q + 16 * i);
@@ -383,16 +399,13 @@ __global__ __launch_bounds__(kBlock) void tail128_coop_kernel(PassArgs a) {
     for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], w(i * q, 1.0f / 128));
     dft<8>(v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      s_out[0][(q + 16 * i) * kCoopCols + c] = static_cast<_Float16>(v[i].re * a.scale);
-      s_out[1][(q + 16 * i) * kCoopCols + c] = static_cast<_Float16>(v[i].im * a.scale);
-    }
+    for (int i = 0; i < 8; ++i) out(q + 16 * i, v[i]);
   }
   __syncthreads();
   {
-    const uint32_t row = t & 127;
-    _Float16* dst = (t < 128 ? a.out_re : a.out_im) + fft * a.out_stride + row * a.m_f + j0;
-    *reinterpret_cast<hv8*>(dst) = *reinterpret_cast<const hv8*>(s_out[t < 128 ? 0 : 1] + row * kCoopCols);
+    const uint32_t row = t & (R - 1);
+    _Float16* dst = (t < R ? a.out_re : a.out_im) + fft * a.out_stride + row * a.m_f + j0;
+    *reinterpret_cast<hv8*>(dst) = *reinterpret_cast<const hv8*>(s_out[t < R ? 0 : 1] + row * kCoopCols);
   }
 }
 

@@ -307,7 +307,7 @@ void plan_passes(uint64_t n, uint64_t inner, int variant, std::vector<Pass>& pas
     const bool fuse_tail = !(variant & 2097152);
     if (fuse_tail && n256 >= 1 && radices.size() >= static_cast<size_t>(n256) + 2) {
       const size_t last = radices.size() - 1;
-      // (... and 2^15 = 256 x 16 x 8 into 256 x 128 with the workgroup-cooperative radix-128 pass, stockham::tail128_coop_kernel)
+      // (... and 2^15 = 256 x 16 x 8 into 256 x 128 with the workgroup-cooperative radix-128 pass, stockham::tail_coop_kernel)
       const bool coop128 = lg == 15 && inner == 1 && n256 == 1 && radices[0] == 256 && radices[last] == 8;
       if (radices[last - 1] == 16 && (radices[last] == 2 || radices[last] == 4 || coop128) && last - 1 == static_cast<size_t>(n256)) {
         radices[last - 1] = 16 * radices[last];
@@ -389,11 +389,23 @@ inline uint32_t rounds_grid(uint64_t blocks, uint32_t capacity, uint32_t launch_
   return static_cast<uint32_t>(std::min<uint64_t>(blocks, capacity));
 }
 
+// Waves per workgroup that take work in the single-pass kernels (one transform, or one group of transforms, per wave): 8 when the
+// batch fills the chip; for `units` wave-tasks that do not, the fewest (1, 2, 4) that still fit one workgroup per CU, so that the
+// tasks spread over the CUs with one wave per SIMD instead of filling a few CUs with two (profiles/r5_small_scan.txt, last part).
+// Variant bit 4194304 keeps the packed shape (A/B).
+inline uint32_t live_waves(const tfft_plan* p, uint64_t units) {
+  if (p->variant & 4194304) return 8;
+  const uint64_t cus = static_cast<uint64_t>(p->num_cus);
+  for (uint32_t live = 1; live <= 4; live *= 2)
+    if (units <= cus * live) return live;
+  return 8;
+}
+
 template <int V>
 int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                    k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
-  const uint32_t blocks_needed =
-      static_cast<uint32_t>((p->batch + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
+  const uint32_t live = live_waves(p, p->batch);
+  const uint32_t blocks_needed = static_cast<uint32_t>((p->batch + live - 1) / live);
   // Workgroups are sized so that each wave runs about two transforms: the second one's HBM->LDS copy flies under
   // the first one's stores, and the hardware dispatcher hands out the remaining workgroups as CUs drain, which keeps
   // the CUs out of lock-step (measured: 256 persistent workgroups 5.3 TB/s, two transforms per wave 6.1 TB/s, one
@@ -406,33 +418,34 @@ int launch_k4096_v(const tfft_plan* p, const void* in_re, const void* in_im, voi
       TFFT_LAUNCH((k4096::fft4096_kernel<V, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                          static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                          static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                         static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
+                         static_cast<uint32_t>(p->batch), live, static_cast<const uint8_t*>(p->d_tables), p->otw);
       return TFFT_OK;
     }
   }
   TFFT_LAUNCH((k4096::fft4096_kernel<V, false>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
+                     static_cast<uint32_t>(p->batch), live, static_cast<const uint8_t*>(p->d_tables), p->otw);
   return TFFT_OK;
 }
 
 int launch_k256(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                 k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   const uint64_t groups = (p->batch + k256::kFftsPerWave - 1) / k256::kFftsPerWave;
-  const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
+  const uint32_t live = live_waves(p, groups);
+  const uint32_t blocks_needed = static_cast<uint32_t>((groups + live - 1) / live);
   static const uint32_t iters_dflt = env_iters("TFFT_K256_ITERS", 2);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
   if (p->otw.n_mask)
     TFFT_LAUNCH(k256::fft256_kernel<true>, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
                        static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                        static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                       static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
+                       static_cast<uint32_t>(p->batch), live, static_cast<const uint8_t*>(p->d_tables), p->otw);
   else
     TFFT_LAUNCH(k256::fft256_kernel<false>, dim3(grid), dim3(k4096::kThreads), k256::kLdsBytes, s,
                        static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                        static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                       static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
+                       static_cast<uint32_t>(p->batch), live, static_cast<const uint8_t*>(p->d_tables), p->otw);
   return TFFT_OK;
 }
 
@@ -440,7 +453,8 @@ template <int R, bool STG>
 int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                    k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
   const uint64_t groups = (p->batch + (16 / R) - 1) / (16 / R);
-  const uint32_t blocks_needed = static_cast<uint32_t>((groups + k4096::kWavesPerBlock - 1) / k4096::kWavesPerBlock);
+  const uint32_t live = live_waves(p, groups);
+  const uint32_t blocks_needed = static_cast<uint32_t>((groups + live - 1) / live);
   static const uint32_t iters_dflt = env_iters("TFFT_K256_ITERS", 2);
   const uint32_t grid = pick_grid(blocks_needed, p->num_cus, plan_iters(p->launch_iters, iters_dflt));
   if constexpr (STG) {
@@ -448,14 +462,14 @@ int launch_k256r_t(const tfft_plan* p, const void* in_re, const void* in_im, voi
       TFFT_LAUNCH((k256r::fft256r_kernel<R, true, true>), dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
                          static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                          static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                         static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
+                         static_cast<uint32_t>(p->batch), live, static_cast<const uint8_t*>(p->d_tables), p->otw);
       return TFFT_OK;
     }
   }
   TFFT_LAUNCH((k256r::fft256r_kernel<R, STG, false>), dim3(grid), dim3(k4096::kThreads), k256r::lds_bytes<R>(), s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                     static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw);
+                     static_cast<uint32_t>(p->batch), live, static_cast<const uint8_t*>(p->d_tables), p->otw);
   return TFFT_OK;
 }
 
@@ -478,7 +492,13 @@ int launch_k256r(const tfft_plan* p, int radix, const void* in_re, const void* i
 template <int R>
 int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, void* out_re, void* out_im,
                     k4096::Addr in_stride, k4096::Addr out_stride, hipStream_t s) {
-  const uint32_t per_wg = k4096::kWavesPerBlock / R;      // transforms per workgroup iteration
+  // transforms per workgroup iteration: 8 / R, or ONE while that still gives every transform a CU of its own (the R waves of a
+  // transform then have the SIMDs to themselves: 2^13 x 4 11.7 -> 7.6 us, 2^14 x 2 12.2 -> 8.5 us)
+  const uint64_t cus = static_cast<uint64_t>(p->num_cus);
+  const uint32_t per_wg = (p->variant & 4194304) ? k4096::kWavesPerBlock / R
+                          : (R < 8 && p->batch <= cus)   ? 1u
+                          : (R == 2 && p->batch <= 2 * cus) ? 2u      // (four waves: still one per SIMD)
+                                                            : k4096::kWavesPerBlock / R;
   const uint32_t blocks_needed = static_cast<uint32_t>((p->batch + per_wg - 1) / per_wg);
   // persistent workgroups: with four workgroup barriers per transform the short-lived launch shape of the 4096
   // kernel does not help here (measured at 2^13: 405 / 425 / 440 / 457 Gsamples/s for 1 / 2 / 4 / all iterations)
@@ -495,12 +515,12 @@ int launch_k4096r_t(const tfft_plan* p, const void* in_re, const void* in_im, vo
     TFFT_LAUNCH((k4096r::fft4096r_kernel<R, false, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                        static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                        static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                       static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw TFFT_NO_STAMPS);
+                       static_cast<uint32_t>(p->batch), per_wg, static_cast<const uint8_t*>(p->d_tables), p->otw TFFT_NO_STAMPS);
   else
     TFFT_LAUNCH((k4096r::fft4096r_kernel<R, false, false>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                        static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                        static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), in_stride, out_stride,
-                       static_cast<uint32_t>(p->batch), static_cast<const uint8_t*>(p->d_tables), p->otw TFFT_NO_STAMPS);
+                       static_cast<uint32_t>(p->batch), per_wg, static_cast<const uint8_t*>(p->d_tables), p->otw TFFT_NO_STAMPS);
 #undef TFFT_NO_STAMPS
   return TFFT_OK;
 }
@@ -526,7 +546,7 @@ int launch_rows2d(const tfft_plan* p, const void* in_re, const void* in_im, void
   TFFT_LAUNCH((k4096r::fft4096r_kernel<8, true>), dim3(grid), dim3(k4096::kThreads), k4096::kLdsBytes, s,
                      static_cast<const uint16_t*>(in_re), static_cast<const uint16_t*>(in_im),
                      static_cast<uint16_t*>(out_re), static_cast<uint16_t*>(out_im), k4096::Addr{image_stride, image_stride, 0, 0},
-                     k4096::Addr{image_stride, image_stride, 0, 0}, iterations, static_cast<const uint8_t*>(p->d_tables), k4096::OutTw{}
+                     k4096::Addr{image_stride, image_stride, 0, 0}, iterations, 1u, static_cast<const uint8_t*>(p->d_tables), k4096::OutTw{}
 #ifdef TFFT_DEBUG_KERNELS
                      , stamps
 #endif
@@ -811,7 +831,9 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   const uint64_t entries = a.tasks / a.groups;
   // narrow pitch (N = 256 pitch contiguous, columns-on-lanes form): a workgroup spans 128 / pitch whole batch
   // entries; entries that do not fill a workgroup go to the per-wave kernel in a second launch.
-  if (wg_allowed && a.ns_f == 1 && a.pitch >= 16 && a.pitch < 128) {
+  // (a few entries of 64 columns, the first pass of a small batch of 2^14 = 256 x 64: the latency kernel below)
+  const bool lat_narrow = a.pitch == 64 && entries <= 64 && tw != colfft::kTwFourStep && !(p->variant & kVarNoLat);
+  if (wg_allowed && a.ns_f == 1 && a.pitch >= 16 && a.pitch < 128 && !lat_narrow) {
     const uint64_t per = 128 / a.pitch;
     const uint64_t main_entries = entries - entries % per;
     if (main_entries) {
@@ -935,14 +957,20 @@ void launch_stockham_pass(const tfft_plan* p, const Pass& ps, Planes src, Planes
       default: launch_pass_pair<8>(a, p->batch, s); return;
     }
   }
-  if (R == 128) {      // (plan_passes emits it only as the last pass behind a column pass that applied its twiddles)
-    if (!a.skip_tw || a.ns != a.m_f || a.m_f % stockham::kCoopCols) {
+  // Workgroup-cooperative final pass (stockham::tail_coop_kernel): radix 128 always (plan_passes emits it only as 2^15 = 256 x 128),
+  // radix 64 for the last pass of 2^14 = 256 x 64 while the batch is small (16-byte row segments: a large batch keeps the
+  // butterfly-per-thread kernel, whose accesses are whole lines)
+  const bool coop_geom = a.skip_tw && a.ns == a.m_f && a.m_f % stockham::kCoopCols == 0 && p->inner == 1;
+  if (R == 128 || (R == 64 && coop_geom && p->n == 16384 && p->batch <= 16 && !(p->variant & 4194304))) {
+    if (!coop_geom) {
       (void)fail(TFFT_ERR_ARG, "internal error: radix-128 pass outside its geometry");
       return;
     }
-    if (!g_prepare)
-      hipLaunchKernelGGL(stockham::tail128_coop_kernel, dim3(static_cast<uint32_t>(a.m_f / stockham::kCoopCols * p->batch)),
-                         dim3(stockham::kBlock), 0, s, a);
+    const dim3 grid(static_cast<uint32_t>(a.m_f / stockham::kCoopCols * p->batch));
+    if (!g_prepare) {
+      if (R == 128) hipLaunchKernelGGL(stockham::tail_coop_kernel<128>, grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(stockham::tail_coop_kernel<64>, grid, dim3(128), 0, s, a);
+    }
     return;
   }
   switch (R) {
@@ -1331,6 +1359,9 @@ inline int small_work_variant(uint64_t n, uint64_t inner, uint64_t batch) {
   // kernel, whose eight 4096-point sub-transforms share ONE CU (profiles/r5_small_scan.txt, last part: x 1: 12.0 -> 7.9 us, x 4:
   // 12.2 -> 8.8, x 8: 12.3 -> 10.3, x 16: 12.3 against 14.6)
   if (lg == 15) return work <= (1ull << 18) ? (kSplit256 | 16777216) : 0;
+  // 2^14 up to 4 transforms: 256 x 64, the same two launches with the cooperative radix-64 pass (x 1: 8.4 -> 7.2 us, x 4: 8.7 -> 7.5,
+  // x 8: 8.6 / 8.3, x 16: 8.8 against 9.9). 2^13 stays on the single-pass kernel (7.7 against 10.0 us).
+  if (lg == 14) return work <= (1ull << 16) ? (kSplit256 | 16777216) : 0;
   if (lg < 17 || lg > 21) return 0;
   if (work <= (lg <= 18 ? (1ull << 20) : (1ull << 22))) return kSplit256;
   if (lg == 18 && work <= (1ull << 22)) return 268435456;  // 512 x 512 with the single-round radix-512 kernel last (round 4: x 16: 32.5 -> 28.4 us)

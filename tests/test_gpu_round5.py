@@ -267,9 +267,41 @@ def test_mfma_flops_are_linear_in_the_batch_across_the_chunk_boundary(tf, lg, or
     assert max(per) - min(per) <= 1e-9 * max(per), per
 
 
+@pytest.mark.parametrize("batch", [1, 3, 4])
+def test_cooperative_radix64_pass(tf, orc, batch):
+    """2^14 = 256 x 64: the latency column kernel on 64 columns, then stockham::tail_coop_kernel<64> (4 x 4 x 4 through LDS): the
+    default for up to 4 transforms. Against orc.dft64 and against the single-pass kernel; with variant bit 4194304 the radix-64 pass
+    runs one butterfly per thread instead: same values to two roundings."""
+    import torch
+
+    n = 1 << 14
+    v = tf.plan_default_variant(n, 1, batch)
+    assert tf.plan_describe(n, 1, v) == "col:256+tw autosort:64-tw"
+    y = _run(tf, torch, n, batch, 150 + batch)
+    assert _check(orc, y, n, batch, 150 + batch) <= REL_L2_TOL
+    for other in (NO_LAT, v | 4194304):          # the single-pass kernel; the butterfly-per-thread radix-64 pass
+        y1 = _run(tf, torch, n, batch, 150 + batch, variant=other)
+        assert _check(orc, y1, n, batch, 150 + batch) <= REL_L2_TOL
+        d = (y.float() - y1.float()).double()
+        assert float(d.norm() / y1.double().norm()) <= 8e-4
+
+
+@pytest.mark.parametrize("n,batch", [(256, 100), (256, 3000), (1024, 40), (2048, 300), (4096, 9), (4096, 700), (8192, 300), (16384, 200)])
+def test_small_batches_spread_over_the_cus(tf, orc, n, batch):
+    """A batch that does not fill the chip runs with fewer working waves per workgroup on more CUs (tfft.hip live_waves, the
+    one-group-per-workgroup form of k4096r): bit-identical to the packed launch shape (variant bit 4194304), every transform
+    written, first / last / a middle one against the oracle."""
+    import torch
+
+    y = _run(tf, torch, n, batch, 170)
+    y_packed = _run(tf, torch, n, batch, 170, variant=4194304)
+    assert bool((y.view(torch.int16) == y_packed.view(torch.int16)).all())
+    assert _check(orc, y, n, batch, 170, ids=(0, batch // 2, batch - 1)) <= REL_L2_TOL
+
+
 @pytest.mark.parametrize("batch", [1, 5, 8])
 def test_cooperative_radix128_pass(tf, orc, batch):
-    """2^15 = 256 x 128: the latency column kernel, then stockham::tail128_coop_kernel (8 columns per workgroup, 4 x 4 x 8 through
+    """2^15 = 256 x 128: the latency column kernel, then stockham::tail_coop_kernel<128> (8 columns per workgroup, 4 x 4 x 8 through
     LDS in fp32): the default for up to 8 transforms. Against orc.dft64, against the single-pass kernel (two roundings apart at
     most), in place, and with padded batch strides on both sides."""
     import torch
