@@ -237,7 +237,7 @@ int tfft_plan_cache_policy(uint64_t n, uint64_t inner, uint64_t batch);
  * as 256 x 256 x 16 with the latency column kernel it takes 18 us): 2^17 ... 2^21 up to 2^20 (2^17, 2^18) / 2^22 (2^19 ... 2^21)
  * samples per launch; 2^18 up to 2^22 samples: the other radix-512 kernel; 2^15 up to 8 transforms: 256 x 128 (8388608 |
  * 33554432 | 16777216: the latency column kernel + a workgroup-cooperative radix-128 pass, 7.3 us for one transform where the
- * single-pass kernel, one CU, takes 11.3); 2^14 up to 4 transforms: 256 x 64 the same way (8.4 -> 7.2 us). Measured limits:
+ * single-pass kernel, one CU, takes 11.3); 2^14 / 2^13 up to 4 transforms: 256 x 64 / 256 x 32 the same way (8.4 -> 7.2, 7.6 -> 7.1 us). Measured limits:
  * profiles/r5_small_scan.txt. The
  * within-noise rules of round 4 (two 2^24, a single 2^25) are wisdom lines now (profiles/r5_TunerResults.dat), not code.
  * Independent of the variant, radix-256 column passes of at most 64 blocks (128 from a row pitch of 512 columns on) run as the

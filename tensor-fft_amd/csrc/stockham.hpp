@@ -317,19 +317,19 @@ __global__ __launch_bounds__(kBlock) void pass_pair_kernel(PassArgs a) {
   }
 }
 
-// Final radix-64 / radix-128 pass of ONE or a few transforms (2^14 = 256 x 64, 2^15 = 256 x 128 behind the latency column kernel,
+// Final radix-32 / 64 / 128 pass of ONE or a few transforms (2^13 = 256 x 32, 2^14 = 256 x 64, 2^15 = 256 x 128 behind the latency column kernel,
 // collat.hpp), workgroup-cooperative: a radix-64 butterfly per THREAD (pass_kernel<64>) leaves a single 2^14 with one workgroup
 // of 256 threads that each grind through a thousand fp32 instructions and 256 two-byte memory instructions (2^14 as 256 x 64:
 // 13.5 us, profiles/r5_lat_shapes.txt). Here a workgroup of 2 R threads takes 8 columns of the [R][m] matrix (16-byte row
 // segments, ONE vector load and ONE vector store per thread) and runs the R-point transforms of those columns as three autosort
-// steps 4 x 4 x 4 (R = 64) or 4 x 4 x 8 (R = 128) through LDS in fp32 (one rounding to binary16, at the end); the input twiddles
+// steps 4 x 8 (R = 32), 4 x 4 x 4 (R = 64) or 4 x 4 x 8 (R = 128) through LDS in fp32 (one rounding to binary16, at the end); the input twiddles
 // were applied by the column pass in front (skip_tw), and because this is the plan's last pass (Ns = m) output row k of column j
 // is element k m + j: the input's own layout. m % 8 == 0. (The same pass for R = 512 ... 2048 loses to the three-launch plans,
 // profiles/r5_coop_tail_radices.txt.)
 constexpr int kCoopCols = 8;
 template <int R>
 __global__ __launch_bounds__(2 * R) void tail_coop_kernel(PassArgs a) {
-  static_assert(R == 64 || R == 128, "4 x 4 x 4 or 4 x 4 x 8");
+  static_assert(R == 32 || R == 64 || R == 128, "4 x 8, 4 x 4 x 4 or 4 x 4 x 8");
   __shared__ float s_re[2][R * kCoopCols];
   __shared__ float s_im[2][R * kCoopCols];
   __shared__ __attribute__((aligned(16))) _Float16 s_out[2][R * kCoopCols];
@@ -370,7 +370,18 @@ __global__ __launch_bounds__(2 * R) void tail_coop_kernel(PassArgs a) {
     for (int i = 0; i < 4; ++i) put(1, 4 * q + i, v[i]);
   }
   __syncthreads();
-  {  // step 2: radix 4, Ns = 4: j = q, k = j & 3, twiddle w_16^(i k), y[(j - k) 4 + k + 4 i]
+  if (R == 32) {
+    if (q < 4) {  // step 2 of 4 x 8: radix 8, Ns = 4: j = k = q < 4, twiddle w_32^(i k), output row k + 4 i
+      cf v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = at(1, q + 4 * i);
+#pragma unroll
+      for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], w(i * q, 1.0f / 32));
+      dft<8>(v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out(q + 4 * i, v[i]);
+    }
+  } else {  // step 2: radix 4, Ns = 4: j = q, k = j & 3, twiddle w_16^(i k), y[(j - k) 4 + k + 4 i]
     const uint32_t k = q & 3;
     cf v[4];
 #pragma unroll
@@ -382,7 +393,8 @@ __global__ __launch_bounds__(2 * R) void tail_coop_kernel(PassArgs a) {
     for (int i = 0; i < 4; ++i) put(0, (q - k) * 4 + k + 4 * i, v[i]);
   }
   __syncthreads();
-  if (R == 64) {  // step 3: radix 4, Ns = 16: j = k = q < 16, twiddle w_64^(i k), output row k + 16 i
+  if (R == 32) {
+  } else if (R == 64) {  // step 3: radix 4, Ns = 16: j = k = q < 16, twiddle w_64^(i k), output row k + 16 i
     cf v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = at(0, q + 16 * i);

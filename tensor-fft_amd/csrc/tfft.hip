@@ -832,7 +832,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   // narrow pitch (N = 256 pitch contiguous, columns-on-lanes form): a workgroup spans 128 / pitch whole batch
   // entries; entries that do not fill a workgroup go to the per-wave kernel in a second launch.
   // (a few entries of 64 columns, the first pass of a small batch of 2^14 = 256 x 64: the latency kernel below)
-  const bool lat_narrow = a.pitch == 64 && entries <= 64 && tw != colfft::kTwFourStep && !(p->variant & kVarNoLat);
+  const bool lat_narrow = (a.pitch == 64 || a.pitch == 32) && entries <= 64 && tw != colfft::kTwFourStep && !(p->variant & kVarNoLat);
   if (wg_allowed && a.ns_f == 1 && a.pitch >= 16 && a.pitch < 128 && !lat_narrow) {
     const uint64_t per = 128 / a.pitch;
     const uint64_t main_entries = entries - entries % per;
@@ -860,10 +860,12 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
   // 20.0 / 17.7, 2^21 x 1: 26.0 / 28.7, 2^17 x 32: 26.7 / 23.3): the throughput kernels keep everything from there on. 128 blocks
   // still win by 7-9 % wherever a row is at least 512 columns wide (2^21 x 1, 2^20 x 2: 26.5 / 28.6, 2^19 x 4: 26.1 / 28.0, 2^18 x 8
   // as 256 x 256 x 4: 25.9 / 27.6) and lose 13 % at a pitch of 256 (2^16 x 32, above).
-  const uint64_t blocks64 = entries * a.pitch / 64;
+  // (in units of 16 columns: a pitch of 32, the first pass of 2^13 = 256 x 32, is two 16-column blocks per entry)
+  const uint64_t blocks16 = entries * a.pitch / 16, blocks64 = (blocks16 + 3) / 4;
+  const bool lat_geom = wg4_ok || (a.pitch == 32 && a.ns_f == 1);
   // (tfft_plan_opts.launch_iters shapes the grids of the grid-stride kernels; this kernel's grid is one workgroup per block either way,
   // so a launch shape never changes WHICH kernel runs, and with it the bits: test_launch_shape_never_changes_results)
-  if (wg_allowed && wg4_ok && tw != colfft::kTwFourStep && !(p->variant & kVarNoLat) && blocks64 <= (a.pitch >= 512 ? 128u : 64u)) {
+  if (wg_allowed && lat_geom && tw != colfft::kTwFourStep && !(p->variant & kVarNoLat) && blocks64 <= (a.pitch >= 512 ? 128u : 64u)) {
     // Workgroup shape (column groups of 16 per workgroup, waves per column group): stage 2 is bound by instruction issue, so the
     // finer the split the shorter the pass - until the row segments get too narrow for the memory system (32-byte segments over
     // 4 MiB: loads land after 2.3 us instead of 0.9, tools/lat_probe). One box, device time per transform, shapes 4 x 2 / 2 x 2 /
@@ -877,7 +879,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     // 12.45 / 12.25, 2^19 14.39 / 13.80 / 14.17, 2^20 18.12 / 17.77 / 20.23, 2^21 (256 workgroups already) 26.0 / 27.5: 2-4 %, and
     // four-way loses what two-way gains (every partner repeats the loads and stage 1). The partners READ the same block and WRITE
     // disjoint bytes of dst: never for a pass in place.
-    const uint32_t wgs = static_cast<uint32_t>(blocks64 * 4 / cgs);
+    const uint32_t wgs = static_cast<uint32_t>(blocks16 / cgs);
     const int pp = (a.in_re != a.out_re && a.in_im != a.out_im && wgs * 2 <= static_cast<uint32_t>(p->num_cus) && 16 / (hh * 2) >= 2) ? 2 : 1;
     int cgs_used = cgs, hh_used = hh, pp_used = pp;
 #ifdef TFFT_DEBUG_KERNELS
@@ -889,7 +891,7 @@ int launch_col(const tfft_plan* p, const Pass& ps, Planes src, Planes dst, hipSt
     }
 #endif
     return launch_col_row(p, col_key(kFamLat, mode, tw, cgs_used, hh_used, pp_used),
-                          static_cast<uint32_t>(blocks64 * 4 / cgs_used) * static_cast<uint32_t>(pp_used), a, s);
+                          static_cast<uint32_t>(blocks16 / cgs_used) * static_cast<uint32_t>(pp_used), a, s);
   }
   // variant bit 524288: 4-wave workgroups (two per CU) instead of one 8-wave workgroup
   static const uint32_t wg4_max_pitch_lanes = env_iters("TFFT_WG4_MAX_PITCH", 1024);          // experiment knobs
@@ -958,10 +960,10 @@ void launch_stockham_pass(const tfft_plan* p, const Pass& ps, Planes src, Planes
     }
   }
   // Workgroup-cooperative final pass (stockham::tail_coop_kernel): radix 128 always (plan_passes emits it only as 2^15 = 256 x 128),
-  // radix 64 for the last pass of 2^14 = 256 x 64 while the batch is small (16-byte row segments: a large batch keeps the
+  // radix 64 / 32 for the last pass of 2^14 = 256 x 64 / 2^13 = 256 x 32 while the batch is small (16-byte row segments: a large batch keeps the
   // butterfly-per-thread kernel, whose accesses are whole lines)
   const bool coop_geom = a.skip_tw && a.ns == a.m_f && a.m_f % stockham::kCoopCols == 0 && p->inner == 1;
-  if (R == 128 || (R == 64 && coop_geom && p->n == 16384 && p->batch <= 16 && !(p->variant & 4194304))) {
+  if (R == 128 || ((R == 64 || R == 32) && coop_geom && p->n == 256ull * R && p->batch <= 16 && !(p->variant & 4194304))) {
     if (!coop_geom) {
       (void)fail(TFFT_ERR_ARG, "internal error: radix-128 pass outside its geometry");
       return;
@@ -969,7 +971,8 @@ void launch_stockham_pass(const tfft_plan* p, const Pass& ps, Planes src, Planes
     const dim3 grid(static_cast<uint32_t>(a.m_f / stockham::kCoopCols * p->batch));
     if (!g_prepare) {
       if (R == 128) hipLaunchKernelGGL(stockham::tail_coop_kernel<128>, grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL(stockham::tail_coop_kernel<64>, grid, dim3(128), 0, s, a);
+      else if (R == 64) hipLaunchKernelGGL(stockham::tail_coop_kernel<64>, grid, dim3(128), 0, s, a);
+      else hipLaunchKernelGGL(stockham::tail_coop_kernel<32>, grid, dim3(64), 0, s, a);
     }
     return;
   }
@@ -1360,8 +1363,10 @@ inline int small_work_variant(uint64_t n, uint64_t inner, uint64_t batch) {
   // 12.2 -> 8.8, x 8: 12.3 -> 10.3, x 16: 12.3 against 14.6)
   if (lg == 15) return work <= (1ull << 18) ? (kSplit256 | 16777216) : 0;
   // 2^14 up to 4 transforms: 256 x 64, the same two launches with the cooperative radix-64 pass (x 1: 8.4 -> 7.2 us, x 4: 8.7 -> 7.5,
-  // x 8: 8.6 / 8.3, x 16: 8.8 against 9.9). 2^13 stays on the single-pass kernel (7.7 against 10.0 us).
+  // x 8: 8.6 / 8.3, x 16: 8.8 against 9.9). 2^13 up to 4 transforms: 256 x 32 likewise (x 1: 7.6 -> 7.1 us, x 4: 7.8 -> 7.2, x 8: 7.8 /
+  // 7.5, x 16: 7.8 against 8.2).
   if (lg == 14) return work <= (1ull << 16) ? (kSplit256 | 16777216) : 0;
+  if (lg == 13) return work <= (1ull << 15) ? (kSplit256 | 16777216) : 0;
   if (lg < 17 || lg > 21) return 0;
   if (work <= (lg <= 18 ? (1ull << 20) : (1ull << 22))) return kSplit256;
   if (lg == 18 && work <= (1ull << 22)) return 268435456;  // 512 x 512 with the single-round radix-512 kernel last (round 4: x 16: 32.5 -> 28.4 us)

@@ -267,16 +267,17 @@ def test_mfma_flops_are_linear_in_the_batch_across_the_chunk_boundary(tf, lg, or
     assert max(per) - min(per) <= 1e-9 * max(per), per
 
 
+@pytest.mark.parametrize("lg", [13, 14])
 @pytest.mark.parametrize("batch", [1, 3, 4])
-def test_cooperative_radix64_pass(tf, orc, batch):
-    """2^14 = 256 x 64: the latency column kernel on 64 columns, then stockham::tail_coop_kernel<64> (4 x 4 x 4 through LDS): the
-    default for up to 4 transforms. Against orc.dft64 and against the single-pass kernel; with variant bit 4194304 the radix-64 pass
-    runs one butterfly per thread instead: same values to two roundings."""
+def test_cooperative_radix64_pass(tf, orc, lg, batch):
+    """2^14 = 256 x 64 (2^13 = 256 x 32): the latency column kernel on 64 (32) columns, then stockham::tail_coop_kernel<64> (<32>)
+    (4 x 4 x 4, 4 x 8 through LDS): the default for up to 4 transforms. Against orc.dft64 and against the single-pass kernel; with
+    variant bit 4194304 the final pass runs one butterfly per thread instead: same values to two roundings."""
     import torch
 
-    n = 1 << 14
+    n = 1 << lg
     v = tf.plan_default_variant(n, 1, batch)
-    assert tf.plan_describe(n, 1, v) == "col:256+tw autosort:64-tw"
+    assert tf.plan_describe(n, 1, v) == "col:256+tw autosort:%d-tw" % (n // 256)
     y = _run(tf, torch, n, batch, 150 + batch)
     assert _check(orc, y, n, batch, 150 + batch) <= REL_L2_TOL
     for other in (NO_LAT, v | 4194304):          # the single-pass kernel; the butterfly-per-thread radix-64 pass

@@ -124,10 +124,12 @@ def test_small_work_gets_the_split_with_more_workgroups():
     # 2^15 up to 8 transforms: 256 x 128 (latency column kernel + the workgroup-cooperative radix-128 pass) instead of the single-pass kernel
     assert V(1 << 15, 1, 1) == (S | 16777216) and V(1 << 15, 1, 8) == (S | 16777216) and V(1 << 15, 1, 16) == 0 and V(1 << 15, 1, 8192) == 0
     assert D(1 << 15, 1, V(1 << 15, 1, 1)) == "col:256+tw autosort:128-tw" and D(1 << 15, 1, 0) == "k4096r:8"
-    # 2^14 up to 4 transforms: 256 x 64 the same way (cooperative radix-64 pass); 2^13 stays on the single-pass kernel
+    # 2^14 / 2^13 up to 4 transforms: 256 x 64 / 256 x 32 the same way (cooperative radix-64 / 32 pass)
     assert V(1 << 14, 1, 1) == (S | 16777216) and V(1 << 14, 1, 4) == (S | 16777216) and V(1 << 14, 1, 8) == 0
     assert D(1 << 14, 1, V(1 << 14, 1, 1)) == "col:256+tw autosort:64-tw"
-    for lg in (8, 12, 13, 16, 22, 24, 25, 26):
+    assert V(1 << 13, 1, 1) == (S | 16777216) and V(1 << 13, 1, 4) == (S | 16777216) and V(1 << 13, 1, 8) == 0
+    assert D(1 << 13, 1, V(1 << 13, 1, 1)) == "col:256+tw autosort:32-tw" and D(1 << 13, 1, 0) == "k4096r:2"
+    for lg in (8, 12, 16, 22, 24, 25, 26):
         assert V(1 << lg, 1, 1) == 0 and V(1 << lg, 1, 2) == 0
     assert V(1 << 20, 64, 1) == 0 and V(3 << 19, 1, 1) == 0 and V(1 << 20, 1, 0) == 0
     for lg, b in ((15, 1), (17, 1), (18, 1), (18, 16), (19, 4), (20, 4), (21, 1)):                          # every value it returns is a variant the library accepts
