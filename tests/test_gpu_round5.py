@@ -243,7 +243,7 @@ for slabs in (1, 2, 4):
     # launches + S send / receive groups cost their launch overheads: the overlap cannot pay here, it must only not cost more than
     # those overheads; what it is FOR - xGMI busy while the next slab computes - needs a node)
     if slabs > 1:
-        assert ms < (ph["pre_ms"] + ph["exchange_ms"] + ph["post_ms"]) * 1.12, "the overlapped transform is much slower than its phases in a row"
+        assert ms < (ph["pre_ms"] + ph["exchange_ms"] + ph["post_ms"]) * 1.3, "the overlapped transform is much slower than its phases in a row"   # (measured 1.02 - 1.08; a wall-clock bound in a test must leave room for a noisy box)
     f.close()
 print("SLABS-OK")
 '''
