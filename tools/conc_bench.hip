@@ -13,14 +13,23 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 // one tile = TILE bytes per plane; every wave moves TILE / W bytes of each plane per tile, 1 KiB per instruction
 template <int SEG, int W, int TILE>
 __global__ __launch_bounds__(64 * W) void k(const uint8_t* in, uint8_t* out, uint64_t pitch, uint32_t blocks_per_entry, uint32_t total,
-                                           uint64_t entry_bytes, uint64_t plane) {
+                                           uint64_t entry_bytes, uint64_t plane, uint32_t order) {
   extern __shared__ uint8_t lds[];
   constexpr int RPI = 1024 / SEG, LPR = SEG / 16, NI = TILE / W / 1024;      // instructions per wave, plane and tile
   constexpr int ROWS = TILE / SEG;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t rnd = 0, pos = blockIdx.x;
   for (uint32_t t = blockIdx.x; t < total;) {
-    const uint32_t e = t / blocks_per_entry, cb = t % blocks_per_entry;
+    // order 0: consecutive tiles = consecutive column blocks of one entry (what the library launches); 1: consecutive tiles =
+    // the same column block of consecutive entries; 2: column blocks in a stride-8 interleave (tile t -> block (t % 8) * bpe / 8 + t / 8)
+    const uint32_t entries = total / blocks_per_entry;
+    uint32_t e = t / blocks_per_entry, cb = t % blocks_per_entry;
+    if (order == 1) {
+      e = t % entries;
+      cb = t / entries;
+    } else if (order == 2) {
+      cb = (cb & 7) * (blocks_per_entry / 8) + (cb >> 3);
+    }
     const uint8_t* src = in + e * entry_bytes + static_cast<uint64_t>(cb) * SEG;
     uint8_t* dst = out + e * entry_bytes + static_cast<uint64_t>(cb) * SEG;
     u4 vr[NI], vi[NI];
@@ -44,7 +53,7 @@ __global__ __launch_bounds__(64 * W) void k(const uint8_t* in, uint8_t* out, uin
 }
 
 template <int SEG, int W, int TILE>
-void run(const uint8_t* in, uint8_t* out, uint64_t pitch, uint64_t plane_bytes, int wg_per_cu, int grid) {
+void run(const uint8_t* in, uint8_t* out, uint64_t pitch, uint64_t plane_bytes, int wg_per_cu, int grid, uint32_t order = 0) {
   constexpr int ROWS = TILE / SEG;
   const uint64_t entry = ROWS * pitch;
   const uint32_t bpe = static_cast<uint32_t>(pitch / SEG);
@@ -55,17 +64,17 @@ void run(const uint8_t* in, uint8_t* out, uint64_t pitch, uint64_t plane_bytes, 
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((k<SEG, W, TILE>), dim3(grid), dim3(64 * W), lds, 0, in, out, pitch, bpe, total, entry, plane_bytes);
+  for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((k<SEG, W, TILE>), dim3(grid), dim3(64 * W), lds, 0, in, out, pitch, bpe, total, entry, plane_bytes, order);
   hipEventRecord(e0);
   const int reps = 10;
-  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((k<SEG, W, TILE>), dim3(grid), dim3(64 * W), lds, 0, in, out, pitch, bpe, total, entry, plane_bytes);
+  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((k<SEG, W, TILE>), dim3(grid), dim3(64 * W), lds, 0, in, out, pitch, bpe, total, entry, plane_bytes, order);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
-  printf("  seg %3d B, tile %3d KiB/plane, %d waves/WG, %d WG/CU, grid %4d (%2d waves per CU on %3d CUs): %8.1f us  %6.0f GB/s\n", SEG, TILE / 1024, W,
-         wg_per_cu, grid, W * wg_per_cu, grid / wg_per_cu > 256 ? 256 : grid / wg_per_cu, ms * 1e3, 4.0 * total * TILE / ms * 1e-6);
+  printf("  seg %3d B, tile %3d KiB/plane, %d waves/WG, %d WG/CU, grid %4d (%2d waves per CU on %3d CUs), order %u: %8.1f us  %6.0f GB/s\n", SEG, TILE / 1024, W,
+         wg_per_cu, grid, W * wg_per_cu, grid / wg_per_cu > 256 ? 256 : grid / wg_per_cu, order, ms * 1e3, 4.0 * total * TILE / ms * 1e-6);
 }
 
 int main(int argc, char** argv) {
@@ -83,6 +92,11 @@ int main(int argc, char** argv) {
       run<128, 8, 65536>(in, out, pitch_arg, plane, 1, grid);      // 512 rows x 128 B
       run<128, 8, 131072>(in, out, pitch_arg, plane, 1, grid);     // 1024 rows x 128 B
       run<256, 8, 65536>(in, out, pitch_arg, plane, 1, grid);      // 256 rows x 256 B
+    }
+    // (tile orders: does it matter WHICH tiles are in flight together?)
+    for (uint32_t order : {1u, 2u}) {
+      run<128, 8, 65536>(in, out, pitch_arg, plane, 1, 256, order);
+      run<256, 8, 65536>(in, out, pitch_arg, plane, 1, 256, order);
     }
     return 0;
   }
