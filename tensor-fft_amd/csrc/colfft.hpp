@@ -520,6 +520,9 @@ __global__ __launch_bounds__(64 * W, 2) void colfft256_wg_kernel(Args a) {
             : "memory");
     }
   };
+  // (Round 5, built behind a macro and A/B-ed in one process: the final 8-wave pass taking the NEXT block through registers,
+  // issued behind barrier C under the read-out and the stores as the radix-512 kernel does, instead of this LDS-DMA behind barrier
+  // D: 2^26 x 16 +1.6 %, 2^17 x 8192 -0.4 %, single 2^26 -0.3 %, 256-point transforms along a strided axis -1.0 %: not kept.)
   const uint32_t blk0 = rot.item();
   if (blk0 < total) copy_in(blk0);
   // constant tables (G operands to LDS, F operands to registers) BEHIND the first block's loads: a workgroup with one or two blocks
