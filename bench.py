@@ -268,17 +268,29 @@ def other_configs(torch, tf, orc, device):
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) / reps / 16 * 1e3)
             ts.sort()
+            # ... and the reference's protocol as it stands (Bench.h:121-142): wall clock around one eager call + device synchronise,
+            # 10 warm-up + 100 timed samples (from Python: ctypes + HIP launch + synchronise, ~15-20 us whatever the transform)
+            wall = []
+            for k in range(110):
+                torch.cuda.synchronize()
+                w0 = time.perf_counter()
+                plan.exec(x, x[n:], y, y[n:])
+                torch.cuda.synchronize()
+                if k >= 10:
+                    wall.append((time.perf_counter() - w0) * 1e6)
+            wall_mean = sum(wall) / len(wall)
             if lg <= 20:
                 err = check_transforms(torch, orc, y, n, 1, [0], seed=SEED + lg)
                 check = f"vs the fp64 oracle: rel-L2 {err:.2e}"
             else:
                 check = check_bins(x, y, n, f"single N=2^{lg}")
-            rows[f"2^{lg}"] = {"device_us": ts[len(ts) // 2], "device_us_min": ts[0], "passes": plan.num_launches,
+            rows[f"2^{lg}"] = {"device_us": ts[len(ts) // 2], "device_us_min": ts[0], "wall_us_eager_call_plus_sync": wall_mean, "passes": plan.num_launches,
                                "plan": tf.plan_describe(n, 1, tf.plan_default_variant(n, 1, 1)), "check": check}
             plan.close()
             del gr
         return {"protocol": "one transform per length (FFTBenchSinlge.cu:11-15); device time per transform, 16 executions per HIP graph, "
-                            "median of 7 rounds; input uniform(-1,1) from the counter-hash generator",
+                            "median of 7 rounds; beside it the reference's own sample (wall clock of one eager call + synchronise, mean of 100, "
+                            "mostly host time); input uniform(-1,1) from the counter-hash generator",
                 "lengths": rows}
 
     cases = (("n256_x_1048576", 256, 1 << 20, "natural"), ("n1024_x_262144", 1024, 1 << 18, "natural"),
